@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- pose-energy evaluations per second of the DFIRE hot path on 1k4c (MI355X).
+
+A "step" is one pass of the hot path over one batch: ONE launch of the batched pose-energy
+kernel (plus its tiny tail kernel) over --batch poses that already live in HBM.  The workload
+is BASELINE.json's metric configuration: the 1k4c membrane system (3413 receptor atoms incl.
+453 membrane beads x 3268 ligand atoms, 11 153 684 atom pairs per pose), DFIRE scoring with the
+synthetic DCparams (the real table is not in the reference mount), poses = the example's 200
+starting poses replicated with seeded 0.25 A translation jitter.
+
+    python bench.py --gpus 1 --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Rank 0 prints ONE JSON line.  `value` = poses evaluated by all ranks / max-over-ranks time.
+`roofline` prices the pair kernel against the HBM roof with ALGORITHMIC bytes:
+bytes/pose = 26*(N_rec+N_lig) + 8*P_cut + 64, P_cut counted on the GPU for the actual batch;
+kernel time from HIP events on the launch stream.  `cpu_baseline` times the CPU oracle
+(oracle/, a loop-for-loop C port of the Rust reference, which cannot be built here) on this
+box's host cores over a bounded sample of the same poses.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def load_case(pkg, workload):
+    g = os.path.join(ROOT, "tests", "golden", workload)
+    if workload == "1k4c":
+        return dict(method="dfire", rec=os.path.join(g, "lightdock_receptor_membrane.pdb"),
+                    lig=os.path.join(g, "lightdock_ligand.pdb"), kw={}, pos=os.path.join(g, "initial_positions_0.dat"))
+    if workload == "1ppe":
+        return dict(method="dfire", rec=os.path.join(g, "lightdock_1ppe_e.pdb"), lig=os.path.join(g, "lightdock_1ppe_i.pdb"),
+                    kw=dict(rec_active=["E.ILE.16"]), pos=os.path.join(g, "initial_positions_0.dat"))
+    raise SystemExit("unknown workload " + workload)
+
+
+def read_positions(path):
+    return np.array([[float(v) for v in line.split(" ")] for line in open(path).read().splitlines()])[:, :7]
+
+
+def cpu_baseline(case, table, poses, budget_s, threads):
+    """Time the CPU oracle (test infrastructure used ONLY as the reported baseline) on `threads`
+    host threads over as many of the bench poses as fit the budget."""
+    orc = ge.oracle()
+    scorer = orc.Scorer(case["method"], case["rec"], case["lig"], potential=table, **case["kw"])
+    t0 = time.perf_counter()
+    scorer.energy_row(poses[0])
+    per_eval = max(time.perf_counter() - t0, 1e-6)
+    n = int(max(threads, min(len(poses), budget_s / per_eval)))
+    n -= n % threads
+    sample = poses[:n]
+    out = np.zeros(n)
+
+    def work(k):
+        for i in range(k, n, threads):
+            out[i] = scorer.energy_row(sample[i])       # ctypes releases the GIL
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "evals/s", "cores": threads, "kind": "port",
+            "sample": "%d of the bench poses, %d threads, %.1f s wall (C oracle -O2, f64, no SIMD intrinsics)" % (n, threads, dt)}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8192, help="poses per GPU per step")
+    ap.add_argument("--workload", default="1k4c")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU-baseline budget in core-seconds (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the pose-energy path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    pkg = ge.package()
+    pkg.init(local)
+    case = load_case(pkg, args.workload)
+    table = pkg.synth.dcparams()
+    scorer = pkg.Scorer.from_pdb(case["method"], case["rec"], case["lig"], potential=table, **case["kw"])
+    info = scorer.kernel_info()
+    base = read_positions(case["pos"])
+    # swarms shard across ranks with no exchange: every rank gets its own, differently seeded batch
+    poses = pkg.synth.jitter(base, args.batch, seed=1000 + rank)
+
+    dev = torch.device("cuda", local)
+    d_poses = torch.from_numpy(poses).to(dev)
+    d_out = torch.empty(args.batch, dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(args.batch, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    scorer.set_stream(stream.cuda_stream)
+
+    def step(counts=False):
+        scorer.energy_batch_device(args.batch, d_poses.data_ptr(), poses.shape[1], d_out.data_ptr(), None,
+                                   d_cnt.data_ptr() if counts else None)
+
+    # P_cut of this batch (counting variant of the kernel, outside the timed region)
+    step(counts=True)
+    torch.cuda.synchronize()
+    p_cut = d_cnt.cpu().numpy().astype(np.int64)
+    algo_bytes_launch = float(info["stream_bytes_per_pose"] * args.batch + 8 * p_cut.sum())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    scorer.enable_timing(True)
+    scorer.pair_kernel_time()          # reset
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = scorer.pair_kernel_time()
+    scorer.enable_timing(False)
+    energies = d_out.cpu().numpy()
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total = args.batch * args.steps * world
+        kern_s = kern_ms / 1e3 / max(launches, 1)
+        achieved = algo_bytes_launch / kern_s / 1e9
+        out = {
+            "metric": "pose-energy evals/sec (DFIRE, %s)" % args.workload,
+            "value": total / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s DFIRE pose-energy batch, %d poses/GPU/step, %d x %d atoms, synthetic DCparams"
+                                   % (args.workload, args.batch, scorer.num_atoms(0), scorer.num_atoms(1)),
+                       "poses_per_step_per_gpu": args.batch, "pair_tests_per_pose": info["pair_tests_per_pose"],
+                       "mean_pairs_in_cutoff": float(p_cut.mean()), "parallelism": "swarm-sharded x%d, no collectives" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": info["pair_kernel_name"], "kernel_ms": 1e3 * kern_s,
+                         "algorithmic_bytes_per_launch": algo_bytes_launch,
+                         "pair_tests_per_s": info["pair_tests_per_pose"] * args.batch / kern_s},
+        }
+        if args.cpu_seconds > 0:
+            threads = os.cpu_count() or 1
+            cb, cpu_e = cpu_baseline(case, table, poses, args.cpu_seconds, threads)
+            out["cpu_baseline"] = cb
+            n = len(cpu_e)
+            rel = float(np.max(np.abs(energies[:n] - cpu_e) / np.maximum(np.abs(cpu_e), 1e-9)))
+            out["parity_max_rel_err_vs_cpu_sample"] = rel
+            if rel > 1e-4:
+                raise SystemExit("parity violated: %g" % rel)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

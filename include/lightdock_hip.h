@@ -1,0 +1,219 @@
+/*
+ * lightdock_hip.h -- C ABI of the MI355X (gfx950) GSO + DFIRE/DNA pose-energy engine.
+ *
+ * This is the drop-in boundary for ONE path of lightdock-rust v0.3.2: the scoring
+ * functions behind `trait Score` and the GSO step that drives them.  Every entry point
+ * names the reference interface it replaces (paths relative to the reference tree).
+ * Plain pointers and sizes only; all floating point is IEEE f64 like the reference.
+ *
+ * Conventions
+ *  - Functions returning `int` return LD_OK (0) or a negative ld_status; functions
+ *    returning a handle return NULL on failure.  ld_last_error() gives the message
+ *    (thread local).  Where the reference panics (exit 101) this library fails the call.
+ *  - The caller keeps ownership of every input array (copied at create); outputs are
+ *    written into caller-provided buffers.
+ *  - A handle is bound to the HIP device current at create time and to one stream
+ *    (ld_scorer_set_stream); it is thread-compatible, not thread-safe, like a
+ *    `&Box<dyn Score>` used from the reference's single worker thread.
+ *  - There is NO CPU fallback: without a usable HIP device create fails loudly.
+ *
+ * Pose row layout (== one line of initial_positions_N.dat, src/swarm.rs:36-52):
+ *    [tx ty tz qw qx qy qz | rec_nm[anm_rec] | lig_nm[anm_lig]]     (f64, row-major)
+ */
+#ifndef LIGHTDOCK_HIP_H
+#define LIGHTDOCK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ld_status {
+    LD_OK = 0,
+    LD_ERR_INVALID = -1,     /* bad argument / inconsistent sizes */
+    LD_ERR_UNSUPPORTED = -2, /* residue/atom/method the scoring function does not know */
+    LD_ERR_IO = -3,          /* file missing / unreadable / malformed */
+    LD_ERR_DEVICE = -4,      /* HIP error or no gfx950 device */
+    LD_ERR_NOMEM = -5
+} ld_status;
+
+/* src/scoring.rs:5-9 `enum Method` */
+typedef enum ld_method { LD_METHOD_DFIRE = 0, LD_METHOD_DNA = 1 } ld_method;
+
+#define LD_DFIRE_TABLE_LEN (169 * 169 * 20) /* src/dfire.rs:216,251 */
+
+const char *ld_last_error(void);
+const char *ld_version(void);
+
+/* Select the HIP device for handles created afterwards on this thread (hipSetDevice).
+ * No counterpart in the reference (CPU only).  device < 0: $LIGHTDOCK_DEVICE or 0. */
+int ld_init(int device);
+int ld_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * Scorer construction from arrays: what a Rust `impl Score` shim hands over after it has
+ * run its own model builder.  Replaces DFIRE::new / DNA::new
+ * (src/dfire.rs:201-234, src/dna.rs:375-408) minus the PDB walk.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ld_molecule {
+    size_t n_atoms;
+    const double *coordinates;        /* n_atoms x 3, == DockingModel.coordinates (src/dfire.rs:106) */
+    const uint32_t *dfire_types;      /* DFIRE: DockingModel.atoms, 0..167 (src/dfire.rs:105); else NULL */
+    const double *ele_charges;        /* DNA: src/dna.rs:245; else NULL */
+    const double *vdw_charges;        /* DNA: src/dna.rs:244 */
+    const double *vdw_radii;          /* DNA: src/dna.rs:243 */
+    size_t n_membrane;                /* DockingModel.membrane (src/dfire.rs:107): atom indices of MMB.BJ beads */
+    const uint32_t *membrane;
+    size_t n_restraint_groups;        /* DockingModel.active_restraints (src/dfire.rs:108) as CSR: */
+    const uint32_t *restraint_offsets;/*   n_restraint_groups + 1 offsets into restraint_atoms */
+    const uint32_t *restraint_atoms;  /*   atom indices, one group per restraint residue found in the PDB */
+    size_t num_anm;                   /* DockingModel.num_anm */
+    const double *nmodes;             /* num_anm x n_atoms x 3, C order (src/dfire.rs:292-299); NULL if num_anm == 0 */
+} ld_molecule;
+
+typedef struct ld_scorer_desc {
+    int method;              /* ld_method */
+    int use_anm;             /* DFIRE.use_anm / DNA.use_anm */
+    ld_molecule receptor;
+    ld_molecule ligand;
+    const double *potential; /* DFIRE: LD_DFIRE_TABLE_LEN values of data/DCparams (src/dfire.rs:236-257) */
+} ld_scorer_desc;
+
+typedef struct ld_scorer ld_scorer;
+
+ld_scorer *ld_scorer_create(const ld_scorer_desc *desc);
+
+/* Same, but with the host-side model builder of this library doing the PDB walk, atom
+ * typing and restraint lookup: DFIRE::new / DNA::new including DFIREDockingModel::new
+ * (src/dfire.rs:115-190) and DNADockingModel::new (src/dna.rs:249-364).  Restraint ids are
+ * "chain.resname.serial[icode]" strings (src/dfire.rs:139-142).  Passive lists are accepted
+ * and ignored exactly like the reference (src/dfire.rs:164-175, never read by energy).
+ * nmodes arrays are the flat contents of rec_nm.npy / lig_nm.npy (may be NULL, len 0). */
+ld_scorer *ld_scorer_create_from_pdb(int method, const char *receptor_pdb, const char *ligand_pdb,
+                                     const char *const *rec_active, size_t n_rec_active,
+                                     const char *const *rec_passive, size_t n_rec_passive,
+                                     const double *rec_nmodes, size_t rec_nmodes_len, size_t rec_num_anm,
+                                     const char *const *lig_active, size_t n_lig_active,
+                                     const char *const *lig_passive, size_t n_lig_passive,
+                                     const double *lig_nmodes, size_t lig_nmodes_len, size_t lig_num_anm,
+                                     int use_anm, const double *potential);
+
+void ld_scorer_destroy(ld_scorer *s); /* Drop of the Box<dyn Score> */
+
+/* ------------------------------------------------------------------------------------
+ * Host-side model builder on its own (no GPU needed): DFIREDockingModel::new
+ * (src/dfire.rs:115-190) / DNADockingModel::new (src/dna.rs:249-364).  The returned view
+ * borrows the model's arrays and is what ld_scorer_create takes.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ld_model ld_model;
+ld_model *ld_model_from_pdb(int method, const char *pdb_path, const char *const *active, size_t n_active,
+                            const char *const *passive, size_t n_passive, const double *nmodes, size_t nmodes_len,
+                            size_t num_anm);
+int ld_model_view(const ld_model *m, ld_molecule *out);
+void ld_model_destroy(ld_model *m);
+
+/* Host-side constants of the DFIRE kernel, exported for tests (DESIGN.md "bin LUT"):
+ * the table bin DIST_TO_BINS[(sqrt(d2)*2-1) as usize]-1 (src/dfire.rs:49-53,336-337) of any
+ * d2 in [0, 225] equals  b = lut[floor(4*d2)];  b += (d2 >= steps[b+1]);
+ * lut: 901 cells of 0.25 A^2; steps[b], b = 0..20: first d2 the reference puts in bin >= b.
+ * interface_d2: the largest d2 whose d = sqrt(d2)*2-1 is <= 3.9 (src/dfire.rs:339). */
+int ld_dfire_bin_lut(uint8_t *lut_out /* 901 */, double *steps_out /* 21 */, double *interface_d2_out);
+/* rand 0.7.3 StdRng::seed_from_u64 -> the 8 ChaCha20 key words the GSO kernel uses (src/lib.rs:38). */
+void ld_stdrng_key(uint64_t seed, uint32_t key_out[8]);
+
+/* DFIRE::load_potentials (src/dfire.rs:236-257): first 169*169*20 lines of a text file. */
+int ld_load_dcparams(const char *path, double *out /* LD_DFIRE_TABLE_LEN */);
+
+/* introspection (host copies of what the model builder produced) */
+size_t ld_scorer_num_atoms(const ld_scorer *s, int side /* 0 receptor, 1 ligand */);
+size_t ld_scorer_pose_len(const ld_scorer *s);  /* 7, or 7 + anm_rec + anm_lig when use_anm */
+int ld_scorer_method(const ld_scorer *s);
+int ld_scorer_model_arrays(const ld_scorer *s, int side, double *coordinates /* n*3 or NULL */,
+                           uint32_t *dfire_types /* n or NULL */, double *ele_charges, double *vdw_charges,
+                           double *vdw_radii);
+
+/* Bind the handle to a HIP stream (hipStream_t passed as void*); NULL = the default
+ * stream.  All *_device calls and kernels of this handle are enqueued there. */
+int ld_scorer_set_stream(ld_scorer *s, void *hip_stream);
+
+/* `Score::energy` (src/scoring.rs:11-19; impls src/dfire.rs:264-363, src/dna.rs:410-529):
+ * one pose in, one f64 out; rec_nm / lig_nm may be NULL when the scorer has no ANM.
+ * Synchronous (host pointers). */
+int ld_scorer_energy(ld_scorer *s, const double translation[3], const double rotation_wxyz[4],
+                     const double *rec_nmodes, const double *lig_nmodes, double *energy_out);
+
+/* Batched form of the same call: what Swarm::update_luciferin (src/swarm.rs:66-70) does
+ * one glowworm at a time.  poses: n rows of `stride` doubles (stride >= pose_len).
+ * Host-pointer version copies in/out and synchronises. */
+int ld_scorer_energy_batch(ld_scorer *s, size_t n, const double *poses, size_t stride, double *energies_out);
+
+/* Device-pointer version: poses and energies already live in HBM (hipMalloc / a torch CUDA
+ * tensor's data_ptr); asynchronous on the handle's stream.  `active` (device, n bytes, may
+ * be NULL) skips poses whose byte is 0 and leaves their output untouched -- this is the
+ * `if self.moved || self.step == 0` of Glowworm::compute_luciferin (src/glowworm.rs:62).
+ * `pair_counts` (device, n x uint32, may be NULL) receives the number of atom pairs inside
+ * the outer cutoff (DFIRE d2 <= 225, src/dfire.rs:334; DNA d2 <= 900, src/dna.rs:481): the
+ * P_cut of the algorithmic-bytes model. */
+int ld_scorer_energy_batch_device(ld_scorer *s, size_t n, const double *d_poses, size_t stride,
+                                  const uint8_t *d_active, double *d_energies_out, uint32_t *d_pair_counts);
+
+/* Per-launch facts for the measurement harness. */
+typedef struct ld_kernel_info {
+    const char *pair_kernel_name; /* symbol of the dominant (pair loop) kernel */
+    uint32_t block_threads;
+    uint32_t receptor_chunks;     /* workgroups per pose */
+    uint32_t lds_bytes;
+    uint64_t pair_tests_per_pose; /* n_rec * n_lig */
+    uint64_t stream_bytes_per_pose; /* algorithmic bytes excluding the 8*P_cut gather term */
+} ld_kernel_info;
+int ld_scorer_kernel_info(const ld_scorer *s, ld_kernel_info *out);
+
+/* Measurement hook: when enabled, every ld_scorer_energy_batch_device call brackets its
+ * pair kernel with HIP events on the handle's stream.  ld_scorer_pair_kernel_time
+ * synchronises those events and returns the summed duration (ms) and launch count since
+ * the last reset; reading also resets. */
+int ld_scorer_enable_timing(ld_scorer *s, int enable);
+int ld_scorer_pair_kernel_time(ld_scorer *s, double *total_ms_out, uint64_t *launches_out);
+
+/* ------------------------------------------------------------------------------------
+ * GSO: batched over independent swarms.  Replaces GSO::new / GSO::run
+ * (src/lib.rs:27-58), Swarm (src/swarm.rs) and Glowworm (src/glowworm.rs).
+ * ---------------------------------------------------------------------------------- */
+typedef struct ld_gso ld_gso;
+
+/* positions: n_swarms x n_glowworms rows of pose_len doubles (src/swarm.rs:26-64).
+ * seeds: one u64 per swarm (GSO::new's `seed`, src/lib.rs:38), or NULL for DEFAULT_SEED
+ * 324324 (src/constants.rs:2) everywhere. */
+ld_gso *ld_gso_create(ld_scorer *scorer, size_t n_swarms, size_t n_glowworms, const double *positions,
+                      const uint64_t *seeds);
+void ld_gso_destroy(ld_gso *g);
+
+/* One iteration of the loop body of GSO::run (src/lib.rs:47-50): update_luciferin
+ * (pose-energy kernel over the glowworms that moved) then movement_phase.  Asynchronous. */
+int ld_gso_step(ld_gso *g);
+/* `steps` iterations back to back (hipGraph replay when available). */
+int ld_gso_run(ld_gso *g, uint32_t steps);
+uint32_t ld_gso_steps_done(const ld_gso *g);
+uint64_t ld_gso_num_evals(ld_gso *g); /* energy evaluations so far, all swarms (synchronises) */
+
+/* Snapshot of one swarm (synchronises).  Any pointer may be NULL.
+ * poses: n_glowworms x pose_len; neighbors = neighbour count of the last movement phase. */
+int ld_gso_read(ld_gso *g, size_t swarm, double *poses, double *luciferin, double *vision_range,
+                double *scoring, int32_t *n_neighbors, int32_t *moved, int32_t *target);
+
+/* Swarm::save (src/swarm.rs:128-167): writes "<dir>/gso_<step>.out" for one swarm. */
+int ld_gso_save(ld_gso *g, size_t swarm, uint32_t step, const char *dir);
+
+/* ------------------------------------------------------------------------------------
+ * The reference command line (src/bin/lightdock-rust.rs:77-333) as a function:
+ *   argv = { prog, setup.json, initial_positions_N.dat, steps, dfire|dna }
+ * Same stdout lines, same files, same "usage errors return 0" behaviour.
+ * ---------------------------------------------------------------------------------- */
+int ld_cli_main(int argc, char **argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGHTDOCK_HIP_H */

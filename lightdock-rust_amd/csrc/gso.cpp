@@ -1,0 +1,141 @@
+#include "gso.hpp"
+
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace ld {
+
+Gso::Gso(Scorer &scorer, size_t n_swarms, size_t n_glowworms, const double *positions, const uint64_t *seeds)
+    : scorer_(scorer), n_swarms_(n_swarms), n_glowworms_(n_glowworms), pose_len_(scorer.pose_len()) {
+    if (n_swarms == 0 || n_glowworms == 0) throw Error(LD_ERR_INVALID, "ld_gso_create: empty swarm");
+    if (!positions) throw Error(LD_ERR_INVALID, "ld_gso_create: positions missing");
+    if (n_glowworms > 4096) throw Error(LD_ERR_INVALID, "ld_gso_create: more than 4096 glowworms per swarm");
+    const size_t total = n_swarms * n_glowworms;
+    if (total > (size_t)1 << 28) throw Error(LD_ERR_INVALID, "ld_gso_create: too many glowworms");
+    if (pose_len_ > 7 + 2 * 64) throw Error(LD_ERR_INVALID, "ld_gso_create: pose row too long");
+
+    std::vector<double> rows(positions, positions + total * pose_len_);
+    poses_[0] = arena_.upload(rows);
+    poses_[1] = arena_.upload(rows);
+    // Glowworm::new defaults, src/glowworm.rs:45-57
+    luciferin_ = arena_.upload(std::vector<double>(total, 5.0));
+    vision_ = arena_.upload(std::vector<double>(total, 0.2));
+    scoring_ = arena_.upload(std::vector<double>(total, 0.0));
+    active_ = arena_.upload(std::vector<uint8_t>(total, 1));  // step == 0: everybody is scored
+    n_neighbors_ = arena_.upload(std::vector<int32_t>(total, 0));
+    std::vector<int32_t> self(total);
+    for (size_t i = 0; i < total; i++) self[i] = (int32_t)(i % n_glowworms);
+    target_ = arena_.upload(self);
+    step_ = arena_.upload(std::vector<uint32_t>(n_swarms, 0));
+    std::vector<uint32_t> keys(8 * n_swarms);
+    for (size_t s = 0; s < n_swarms; s++) stdrng_key_from_seed(seeds ? seeds[s] : 324324ULL, &keys[8 * s]);  // src/lib.rs:38
+    rng_key_ = arena_.upload(keys);
+    evals_ = arena_.upload(std::vector<unsigned long long>(1, (unsigned long long)total));
+}
+
+Gso::~Gso() {}
+
+void Gso::step() {
+    // Swarm::update_luciferin (src/swarm.rs:66-70): energies only for glowworms that moved
+    // (or all of them at step 0); the luciferin arithmetic itself is folded into K2.
+    scorer_.energy_batch_device(n_swarms_ * n_glowworms_, poses_[cur_], pose_len_, active_, scoring_, nullptr);
+    GsoLaunch g;
+    g.n_swarms = (int)n_swarms_;
+    g.n_glowworms = (int)n_glowworms_;
+    g.pose_len = (int)pose_len_;
+    g.anm_rec = (int)scorer_.anm_rec();
+    g.anm_lig = (int)scorer_.anm_lig();
+    g.poses_in = poses_[cur_];
+    g.poses_out = poses_[cur_ ^ 1];
+    g.luciferin = luciferin_;
+    g.vision = vision_;
+    g.scoring = scoring_;
+    g.active = active_;
+    g.n_neighbors = n_neighbors_;
+    g.target = target_;
+    g.step = step_;
+    g.rng_key = rng_key_;
+    g.evals = evals_;
+    hip_check(launch_gso_step(g, scorer_.stream()), "launch gso_movement_phase");
+    cur_ ^= 1;
+    steps_done_++;
+}
+
+void Gso::run(uint32_t steps) {
+    for (uint32_t s = 0; s < steps; s++) step();
+}
+
+uint64_t Gso::num_evals() {
+    // evals_ starts at S*N (the step-0 evaluation of everybody) and K2 adds the glowworms it
+    // moved, i.e. the evaluations of the NEXT step; subtract the ones not yet performed.
+    unsigned long long total = 0;
+    hip_check(hipStreamSynchronize(scorer_.stream()), "hipStreamSynchronize");
+    hip_check(hipMemcpy(&total, evals_, sizeof total, hipMemcpyDeviceToHost), "D2H evals");
+    if (steps_done_ == 0) return 0;
+    std::vector<uint8_t> pending(n_swarms_ * n_glowworms_);
+    hip_check(hipMemcpy(pending.data(), active_, pending.size(), hipMemcpyDeviceToHost), "D2H active");
+    unsigned long long not_yet = 0;
+    for (uint8_t a : pending) not_yet += a;
+    return total - not_yet;
+}
+
+void Gso::read(size_t swarm, double *poses, double *luciferin, double *vision, double *scoring, int32_t *n_neighbors,
+               int32_t *moved, int32_t *target) {
+    if (swarm >= n_swarms_) throw Error(LD_ERR_INVALID, "ld_gso_read: swarm index out of range");
+    hip_check(hipStreamSynchronize(scorer_.stream()), "hipStreamSynchronize");
+    const size_t n = n_glowworms_, off = swarm * n;
+    auto pull = [&](void *dst, const void *src, size_t bytes) {
+        if (dst) hip_check(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "D2H state");
+    };
+    pull(poses, poses_[cur_] + off * pose_len_, n * pose_len_ * sizeof(double));
+    pull(luciferin, luciferin_ + off, n * sizeof(double));
+    pull(vision, vision_ + off, n * sizeof(double));
+    pull(scoring, scoring_ + off, n * sizeof(double));
+    pull(n_neighbors, n_neighbors_ + off, n * sizeof(int32_t));
+    pull(target, target_ + off, n * sizeof(int32_t));
+    if (moved) {
+        std::vector<uint8_t> a(n);
+        pull(a.data(), active_ + off, n);
+        // before the first step `active` means "score me", not "moved" (src/glowworm.rs:55)
+        for (size_t i = 0; i < n; i++) moved[i] = steps_done_ == 0 ? 0 : a[i];
+    }
+}
+
+namespace {
+// Rust `{:.N}` == C "%.Nf" (exact decimal expansion, ties to even) except for non-finite values.
+std::string fixed(double v, int prec) {
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    char buf[400];
+    std::snprintf(buf, sizeof buf, "%.*f", prec, v);
+    return buf;
+}
+}  // namespace
+
+void Gso::save(size_t swarm, uint32_t step, const std::string &dir) {
+    const size_t n = n_glowworms_;
+    std::vector<double> poses(n * pose_len_), luc(n), vis(n), sco(n);
+    std::vector<int32_t> nn(n);
+    read(swarm, poses.data(), luc.data(), vis.data(), sco.data(), nn.data(), nullptr, nullptr);
+    const std::string path = dir + "/gso_" + std::to_string(step) + ".out";
+    std::FILE *f = std::fopen(path.c_str(), "w");
+    if (!f) throw Error(LD_ERR_IO, "Error saving GSO output: " + path + ": " + std::strerror(errno));
+    std::fputs("#Coordinates  RecID  LigID  Luciferin  Neighbor's number  Vision Range  Scoring\n", f);
+    for (size_t i = 0; i < n; i++) {
+        const double *row = &poses[i * pose_len_];
+        std::string line = "(";
+        // 7 pose columns, then the ANM extents when the run uses them (src/swarm.rs:136-158)
+        for (size_t c = 0; c < pose_len_; c++) {
+            if (c) line += ", ";
+            line += fixed(row[c], 7);
+        }
+        line += ")    0    0   " + fixed(luc[i], 8) + "  " + std::to_string(nn[i]) + " " + fixed(vis[i], 3) + " " +
+                fixed(sco[i], 8) + "\n";
+        std::fputs(line.c_str(), f);
+    }
+    if (std::fclose(f) != 0) throw Error(LD_ERR_IO, "Error saving GSO output: " + path);
+}
+
+}  // namespace ld

@@ -1,0 +1,54 @@
+// gso.hpp -- the object behind an `ld_gso*`: device-resident state of a batch of
+// independent swarms and the per-step launch sequence K1 (pose energies of the glowworms
+// that moved) -> K2 (movement phase).  Mirrors GSO / Swarm / Glowworm of the reference
+// (src/lib.rs:21-58, src/swarm.rs:9-167, src/glowworm.rs:6-58) as structure-of-arrays.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "kernels/gso_step.hpp"
+#include "scorer.hpp"
+
+namespace ld {
+
+class Gso {
+   public:
+    Gso(Scorer &scorer, size_t n_swarms, size_t n_glowworms, const double *positions, const uint64_t *seeds);
+    ~Gso();
+    Gso(const Gso &) = delete;
+    Gso &operator=(const Gso &) = delete;
+
+    void step();
+    void run(uint32_t steps);
+    uint32_t steps_done() const { return steps_done_; }
+    uint64_t num_evals();
+    size_t n_swarms() const { return n_swarms_; }
+    size_t n_glowworms() const { return n_glowworms_; }
+    size_t pose_len() const { return pose_len_; }
+    void read(size_t swarm, double *poses, double *luciferin, double *vision, double *scoring, int32_t *n_neighbors,
+              int32_t *moved, int32_t *target);
+    void save(size_t swarm, uint32_t step, const std::string &dir);  // Swarm::save, src/swarm.rs:128-167
+
+   private:
+    Scorer &scorer_;
+    size_t n_swarms_, n_glowworms_, pose_len_;
+    uint32_t steps_done_ = 0;
+    DeviceArena arena_;
+    double *poses_[2] = {nullptr, nullptr};
+    int cur_ = 0;
+    double *luciferin_ = nullptr, *vision_ = nullptr, *scoring_ = nullptr;
+    uint8_t *active_ = nullptr;
+    int32_t *n_neighbors_ = nullptr, *target_ = nullptr;
+    uint32_t *step_ = nullptr, *rng_key_ = nullptr;
+    unsigned long long *evals_ = nullptr;
+};
+
+}  // namespace ld
+
+struct ld_gso {
+    ld::Gso impl;
+    ld_gso(ld::Scorer &s, size_t n_swarms, size_t n_glowworms, const double *positions, const uint64_t *seeds)
+        : impl(s, n_swarms, n_glowworms, positions, seeds) {}
+};

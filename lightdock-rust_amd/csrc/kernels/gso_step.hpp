@@ -1,0 +1,40 @@
+// gso_step.hpp -- launch interface of K2, the batched GSO movement kernel.
+//
+// One workgroup per swarm, one thread per glowworm.  Covers, for every swarm at once, the
+// second half of Glowworm::compute_luciferin (src/glowworm.rs:70-71) and the whole of
+// Swarm::movement_phase (src/swarm.rs:72-126).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace ld {
+
+struct GsoLaunch {
+    int n_swarms = 0;
+    int n_glowworms = 0;  // per swarm
+    int pose_len = 0;     // 7 + anm_rec + anm_lig
+    int anm_rec = 0, anm_lig = 0;
+    // state, indexed [swarm * n_glowworms + glowworm]
+    const double *poses_in = nullptr;  // pre-move snapshot (rows of pose_len)
+    double *poses_out = nullptr;       // post-move poses
+    double *luciferin = nullptr;
+    double *vision = nullptr;
+    const double *scoring = nullptr;
+    uint8_t *active = nullptr;        // out: moved flag == "re-score next step" (src/glowworm.rs:62)
+    int32_t *n_neighbors = nullptr;
+    int32_t *target = nullptr;
+    uint32_t *step = nullptr;         // per swarm: completed steps; advanced by the kernel
+    const uint32_t *rng_key = nullptr;  // per swarm: 8 ChaCha key words (rand 0.7.3 StdRng)
+    unsigned long long *evals = nullptr;  // running count of energy evaluations (adds #moved)
+};
+
+size_t gso_kernel_lds_bytes(const GsoLaunch &g);
+hipError_t launch_gso_step(const GsoLaunch &g, hipStream_t stream);
+
+// rand_core 0.5 SeedableRng::seed_from_u64: PCG32 expansion of a u64 into the ChaCha key
+void stdrng_key_from_seed(uint64_t seed, uint32_t key[8]);
+
+}  // namespace ld

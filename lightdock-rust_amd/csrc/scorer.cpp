@@ -1,0 +1,405 @@
+#include "scorer.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+namespace ld {
+
+// ---------------------------------------------------------------------------------------
+// device memory helpers
+// ---------------------------------------------------------------------------------------
+DeviceArena::~DeviceArena() {
+    for (void *p : blocks_) (void)hipFree(p);
+}
+void *DeviceArena::alloc_bytes(size_t bytes) {
+    void *p = nullptr;
+    hip_check(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc");
+    blocks_.push_back(p);
+    return p;
+}
+void DeviceBuffer::reserve(size_t want) {
+    if (want <= bytes) return;
+    release();
+    size_t grow = want + want / 4 + 256;
+    hip_check(hipMalloc(&ptr, grow), "hipMalloc(workspace)");
+    bytes = grow;
+}
+void DeviceBuffer::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// DFIRE distance binning
+// ---------------------------------------------------------------------------------------
+namespace {
+// DIST_TO_BINS (src/dfire.rs:49-53) in closed form for the reachable indices 0..29 (d <= 29):
+// half-angstrom bins up to 8 A, then one-angstrom bins; value = bin + 1.
+int dist_to_bins(size_t idx) {
+    if (idx < 3) return 1;
+    if (idx < 15) return (int)idx - 1;
+    if (idx < 49) return 14 + (int)(idx - 15) / 2;
+    return idx == 49 ? 31 : 32;
+}
+}  // namespace
+
+int dfire_bin_reference(double dist2) {
+    const double d = std::sqrt(dist2) * 2.0 - 1.0;  // src/dfire.rs:336
+    size_t idx = d > 0.0 ? (size_t)d : 0;            // `d as usize` saturates negatives/NaN to 0
+    if (idx > 50) idx = 50;
+    return dist_to_bins(idx) - 1;
+}
+
+// Smallest double x in [0, 225] for which pred(x) holds, pred monotone (false..true).
+template <typename Pred>
+static double first_true(Pred pred) {
+    double lo = 0.0, hi = 225.0;
+    if (pred(lo)) return lo;
+    if (!pred(hi)) return std::numeric_limits<double>::infinity();
+    uint64_t a, b;
+    std::memcpy(&a, &lo, 8);
+    std::memcpy(&b, &hi, 8);
+    while (b - a > 1) {  // positive doubles order like their bit patterns
+        const uint64_t mid = a + (b - a) / 2;
+        double m;
+        std::memcpy(&m, &mid, 8);
+        if (pred(m)) b = mid; else a = mid;
+    }
+    double out;
+    std::memcpy(&out, &b, 8);
+    return out;
+}
+
+DfireBinning build_dfire_binning() {
+    // The bin index floor(2r - 1) steps at r = (k+1)/2, i.e. near d2 = (k+1)^2/4 -- a multiple
+    // of 0.25 -- so the bin at the lower edge of a 0.25-wide d2 cell is right for the whole
+    // cell EXCEPT possibly its very last double: the correctly rounded sqrt may round the
+    // predecessor of a step up onto it.  So: lut[cell] = bin at the cell's lower edge, and
+    // step[b] = the exact first double that the reference formula puts in bin >= b (found by
+    // bisection on the formula itself); bin(d2) = lut[cell] + (d2 >= step[lut[cell] + 1]).
+    DfireBinning t;
+    t.lut.assign(kDfireLutCells, 0);
+    for (int c = 0; c <= 900; c++) t.lut[c] = (uint8_t)dfire_bin_reference(c * 0.25);
+    for (int c = 901; c < kDfireLutCells; c++) t.lut[c] = t.lut[900];
+    t.step.assign(kDfireSteps, std::numeric_limits<double>::infinity());
+    t.step[0] = 0.0;
+    for (int b = 1; b <= 20; b++) t.step[b] = first_true([b](double d2) { return dfire_bin_reference(d2) >= b; });
+    // self-check on both ends of every cell
+    for (int c = 0; c < 900; c++) {
+        const double ends[2] = {c * 0.25, std::nextafter((c + 1) * 0.25, 0.0)};
+        for (double d2 : ends) {
+            const int cell = (int)(d2 * 4.0);
+            int b = t.lut[cell];
+            if (d2 >= t.step[b + 1]) b++;
+            if (cell != c || b != dfire_bin_reference(d2))
+                throw Error(LD_ERR_INVALID, "DFIRE binning self-check failed in cell " + std::to_string(c));
+        }
+    }
+    return t;
+}
+
+double dfire_interface_d2() {
+    // Largest double d2 with fl(fl(sqrt(d2)) * 2 - 1) <= 3.9 (src/dfire.rs:336,339).  The
+    // left side is monotone in d2, so bisect on the bit pattern.
+    auto inside = [](double d2) { return std::sqrt(d2) * 2.0 - 1.0 <= 3.9; };
+    double lo = 0.0, hi = 225.0;  // inside(lo), !inside(hi)
+    uint64_t a, b;
+    std::memcpy(&a, &lo, 8);
+    std::memcpy(&b, &hi, 8);
+    while (b - a > 1) {
+        uint64_t mid = a + (b - a) / 2;
+        double m;
+        std::memcpy(&m, &mid, 8);
+        if (inside(m)) a = mid; else b = mid;
+    }
+    double out;
+    std::memcpy(&out, &a, 8);
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------
+// Scorer
+// ---------------------------------------------------------------------------------------
+namespace {
+
+void check_molecule(const ld_molecule &m, int method, const char *who, bool use_anm) {
+    const std::string w(who);
+    if (m.n_atoms == 0) throw Error(LD_ERR_INVALID, w + ": molecule has no atoms");
+    if (m.n_atoms > (size_t)1 << 24) throw Error(LD_ERR_INVALID, w + ": too many atoms");
+    if (!m.coordinates) throw Error(LD_ERR_INVALID, w + ": coordinates missing");
+    if (method == LD_METHOD_DFIRE) {
+        if (!m.dfire_types) throw Error(LD_ERR_INVALID, w + ": dfire_types missing");
+        for (size_t i = 0; i < m.n_atoms; i++)
+            if (m.dfire_types[i] > 167) throw Error(LD_ERR_INVALID, w + ": DFIRE atom type out of range");
+    } else {
+        if (!m.ele_charges || !m.vdw_charges || !m.vdw_radii) throw Error(LD_ERR_INVALID, w + ": DNA parameters missing");
+    }
+    if (m.n_membrane && !m.membrane) throw Error(LD_ERR_INVALID, w + ": membrane indices missing");
+    for (size_t k = 0; k < m.n_membrane; k++)
+        if (m.membrane[k] >= m.n_atoms) throw Error(LD_ERR_INVALID, w + ": membrane index out of range");
+    if (m.n_restraint_groups) {
+        if (!m.restraint_offsets || !m.restraint_atoms) throw Error(LD_ERR_INVALID, w + ": restraint CSR missing");
+        for (size_t g = 0; g < m.n_restraint_groups; g++)
+            if (m.restraint_offsets[g] > m.restraint_offsets[g + 1]) throw Error(LD_ERR_INVALID, w + ": restraint offsets not sorted");
+        for (uint32_t k = 0; k < m.restraint_offsets[m.n_restraint_groups]; k++)
+            if (m.restraint_atoms[k] >= m.n_atoms) throw Error(LD_ERR_INVALID, w + ": restraint atom out of range");
+    }
+    if (use_anm && m.num_anm > 0 && !m.nmodes) throw Error(LD_ERR_INVALID, w + ": ANM modes missing");
+    if (m.num_anm > 64) throw Error(LD_ERR_INVALID, w + ": more than 64 ANM modes");
+}
+
+}  // namespace
+
+void Scorer::upload_molecule(const ld_molecule &m, bool is_receptor, DeviceMolecule &dev, HostMolecule &host,
+                             std::vector<uint32_t> &group_offsets, std::vector<uint32_t> &group_slots,
+                             std::vector<uint32_t> &membrane_slots) {
+    const size_t n = m.n_atoms;
+    const size_t n_pad = (n + 63) / 64 * 64;
+    dev.n = (int)n;
+    dev.n_pad = (int)n_pad;
+
+    host.coordinates.assign(m.coordinates, m.coordinates + 3 * n);
+    std::vector<double> x(n_pad, 0.0), y(n_pad, 0.0), z(n_pad, 0.0);
+    for (size_t i = 0; i < n; i++) {
+        x[i] = m.coordinates[3 * i];
+        y[i] = m.coordinates[3 * i + 1];
+        z[i] = m.coordinates[3 * i + 2];
+    }
+    dev.x = arena_.upload(x);
+    dev.y = arena_.upload(y);
+    dev.z = arena_.upload(z);
+
+    if (method_ == LD_METHOD_DFIRE) {
+        host.dfire_types.assign(m.dfire_types, m.dfire_types + n);
+        std::vector<uint32_t> t(n_pad, 0);
+        // potential[atoma*169*20 + atomb*20 + bin] (src/dfire.rs:338): receptor carries the
+        // row base, ligand the column base.
+        for (size_t i = 0; i < n; i++) t[i] = m.dfire_types[i] * (is_receptor ? kDfireRowStride : 20u);
+        dev.tindex = arena_.upload(t);
+    } else {
+        host.ele_charges.assign(m.ele_charges, m.ele_charges + n);
+        host.vdw_charges.assign(m.vdw_charges, m.vdw_charges + n);
+        host.vdw_radii.assign(m.vdw_radii, m.vdw_radii + n);
+        dev.charge = arena_.upload(host.ele_charges, n_pad);
+        dev.well_depth = arena_.upload(host.vdw_charges, n_pad);
+        dev.radius = arena_.upload(host.vdw_radii, n_pad);
+    }
+
+    // Interface flags are only needed for restraint atoms and membrane beads
+    // (src/scoring.rs:21-47): give each such atom one bit ("slot") of the per-pose flag set.
+    std::vector<int32_t> slot(n_pad, -1);
+    uint32_t next = 0;
+    auto slot_of = [&](uint32_t atom) {
+        if (slot[atom] < 0) slot[atom] = (int32_t)next++;
+        return (uint32_t)slot[atom];
+    };
+    group_offsets.assign(1, 0);
+    group_slots.clear();
+    for (size_t g = 0; g < m.n_restraint_groups; g++) {
+        for (uint32_t k = m.restraint_offsets[g]; k < m.restraint_offsets[g + 1]; k++)
+            group_slots.push_back(slot_of(m.restraint_atoms[k]));
+        group_offsets.push_back((uint32_t)group_slots.size());
+    }
+    membrane_slots.clear();
+    for (size_t k = 0; k < m.n_membrane; k++) membrane_slots.push_back(slot_of(m.membrane[k]));
+    dev.slot = arena_.upload(slot);
+    dev.flag_words = (int)((next + 31) / 32);
+
+    dev.num_anm = 0;
+    dev.modes = nullptr;
+    if (use_anm_ && m.num_anm > 0) {
+        // (mode, atom, xyz) -> [mode][xyz][n_pad]
+        std::vector<double> modes(m.num_anm * 3 * n_pad, 0.0);
+        for (size_t k = 0; k < m.num_anm; k++)
+            for (size_t i = 0; i < n; i++)
+                for (int c = 0; c < 3; c++) modes[(k * 3 + c) * n_pad + i] = m.nmodes[k * n * 3 + i * 3 + c];
+        dev.modes = arena_.upload(modes);
+        dev.num_anm = (int)m.num_anm;
+    }
+}
+
+Scorer::Scorer(const ld_scorer_desc &desc) {
+    if (desc.method != LD_METHOD_DFIRE && desc.method != LD_METHOD_DNA)
+        throw Error(LD_ERR_UNSUPPORTED, "Error: method not supported");
+    method_ = desc.method;
+    use_anm_ = desc.use_anm != 0;
+    check_molecule(desc.receptor, method_, "receptor", use_anm_);
+    check_molecule(desc.ligand, method_, "ligand", use_anm_);
+    if (method_ == LD_METHOD_DFIRE && !desc.potential) throw Error(LD_ERR_IO, "Unable to open DFIRE parameters");
+
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        throw Error(LD_ERR_DEVICE, "no HIP device available: the pose-energy path has no CPU fallback");
+    hip_check(hipGetDevice(&device_), "hipGetDevice");
+    hipDeviceProp_t prop;
+    hip_check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("LIGHTDOCK_ALLOW_ANY_ARCH"))
+        throw Error(LD_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+
+    std::vector<uint32_t> rgo, rgs, rms, lgo, lgs, lms;
+    upload_molecule(desc.receptor, true, pair_.rec, host_rec_, rgo, rgs, rms);
+    upload_molecule(desc.ligand, false, pair_.lig, host_lig_, lgo, lgs, lms);
+    // src/scoring.rs:38-47 is only ever applied to the receptor (src/dfire.rs:357); ligand
+    // beads get a slot but no reader.
+    tail_.n_rec_groups = (int)rgo.size() - 1;
+    tail_.n_lig_groups = (int)lgo.size() - 1;
+    tail_.n_membrane = (int)rms.size();
+    tail_.rec_group_offsets = arena_.upload(rgo);
+    tail_.rec_group_slots = arena_.upload(rgs);
+    tail_.lig_group_offsets = arena_.upload(lgo);
+    tail_.lig_group_slots = arena_.upload(lgs);
+    tail_.membrane_slots = arena_.upload(rms);
+
+    pair_.method = method_;
+    pair_.use_anm = use_anm_ ? 1 : 0;
+    if (method_ == LD_METHOD_DFIRE) {
+        std::vector<double> table(desc.potential, desc.potential + LD_DFIRE_TABLE_LEN);
+        pair_.table = arena_.upload(table);
+        const DfireBinning binning = build_dfire_binning();
+        pair_.lut = arena_.upload(binning.lut);
+        pair_.bin_step = arena_.upload(binning.step);
+        pair_.iface_d2 = dfire_interface_d2();
+    } else {
+        pair_.iface_d2 = 3.9 * 3.9;  // INTERFACE_CUTOFF2, src/constants.rs:15
+    }
+
+    // Receptor chunking: <= 512 (DFIRE) / 256 (DNA) atoms per workgroup = 16 KiB of LDS
+    // records, balanced over the chunks.  Fixed per scorer so that a pose's energy does not
+    // depend on the batch it is evaluated in.
+    int max_chunk = method_ == LD_METHOD_DFIRE ? 512 : 256;
+    if (const char *e = std::getenv("LIGHTDOCK_CHUNK_ATOMS")) {
+        int v = std::atoi(e);
+        if (v >= 64 && v <= 2048) max_chunk = v;
+    }
+    pair_.n_chunks = (pair_.rec.n + max_chunk - 1) / max_chunk;
+    pair_.chunk_atoms = (pair_.rec.n + pair_.n_chunks - 1) / pair_.n_chunks;
+    const int n_groups = (pair_.lig.n + 63) / 64;
+    pair_.split_j = (n_groups % kWaves != 0 && n_groups < 4 * kWaves) ? 1 : 0;
+}
+
+Scorer::~Scorer() {
+    for (auto &e : events_) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    ws_partial_.release();
+    ws_flags_.release();
+    ws_counts_.release();
+    ws_poses_.release();
+    ws_energies_.release();
+}
+
+void Scorer::reserve_workspace(size_t n_poses, bool counts) {
+    const size_t words = (size_t)(pair_.rec.flag_words + pair_.lig.flag_words);
+    ws_partial_.reserve(n_poses * pair_.n_chunks * 2 * sizeof(double));
+    ws_flags_.reserve(std::max<size_t>(n_poses * words * sizeof(uint32_t), 16));
+    if (counts) ws_counts_.reserve(n_poses * pair_.n_chunks * sizeof(uint32_t));
+}
+
+void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride, const uint8_t *d_active,
+                                 double *d_energies, uint32_t *d_pair_counts) {
+    if (n == 0) return;
+    if (!d_poses || !d_energies) throw Error(LD_ERR_INVALID, "energy_batch: null pose/energy buffer");
+    if (stride < pose_len()) throw Error(LD_ERR_INVALID, "energy_batch: stride shorter than a pose row");
+    reserve_workspace(n, d_pair_counts != nullptr);
+
+    PairLaunch p = pair_;
+    p.poses = d_poses;
+    p.stride = stride;
+    p.active = d_active;
+    p.n_poses = n;
+    p.partial = static_cast<double *>(ws_partial_.ptr);
+    p.flags = static_cast<uint32_t *>(ws_flags_.ptr);
+    p.count_partial = d_pair_counts ? static_cast<uint32_t *>(ws_counts_.ptr) : nullptr;
+
+    const size_t words = (size_t)(p.rec.flag_words + p.lig.flag_words);
+    if (words > 0) hip_check(hipMemsetAsync(p.flags, 0, n * words * sizeof(uint32_t), stream_), "hipMemsetAsync(flags)");
+    if (timing_) {
+        if (events_used_ == events_.size()) {
+            if (events_.size() >= 4096) {  // fold what is pending so the pool stays bounded
+                double ms;
+                uint64_t n;
+                pair_kernel_time(&ms, &n);
+                timed_ms_ = ms;
+                timed_launches_ = n;
+            } else {
+                hipEvent_t a, b;
+                hip_check(hipEventCreate(&a), "hipEventCreate");
+                hip_check(hipEventCreate(&b), "hipEventCreate");
+                events_.emplace_back(a, b);
+            }
+        }
+        hip_check(hipEventRecord(events_[events_used_].first, stream_), "hipEventRecord");
+    }
+    hip_check(launch_pair_kernel(p, stream_), "launch pose_energy_pairs");
+    if (timing_) {
+        hip_check(hipEventRecord(events_[events_used_].second, stream_), "hipEventRecord");
+        events_used_++;
+    }
+
+    FinishLaunch f;
+    f.method = method_;
+    f.n_chunks = p.n_chunks;
+    f.rec_flag_words = p.rec.flag_words;
+    f.lig_flag_words = p.lig.flag_words;
+    f.tail = tail_;
+    f.partial = p.partial;
+    f.flags = p.flags;
+    f.count_partial = p.count_partial;
+    f.active = d_active;
+    f.n_poses = n;
+    f.energies = d_energies;
+    f.pair_counts = d_pair_counts;
+    hip_check(launch_finish_kernel(f, stream_), "launch pose_energy_finish");
+}
+
+void Scorer::energy_batch_host(size_t n, const double *poses, size_t stride, double *energies) {
+    if (n == 0) return;
+    if (!poses || !energies) throw Error(LD_ERR_INVALID, "energy_batch: null pose/energy buffer");
+    ws_poses_.reserve(n * stride * sizeof(double));
+    ws_energies_.reserve(n * sizeof(double));
+    hip_check(hipMemcpyAsync(ws_poses_.ptr, poses, n * stride * sizeof(double), hipMemcpyHostToDevice, stream_), "H2D poses");
+    energy_batch_device(n, static_cast<const double *>(ws_poses_.ptr), stride, nullptr,
+                        static_cast<double *>(ws_energies_.ptr), nullptr);
+    hip_check(hipMemcpyAsync(energies, ws_energies_.ptr, n * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H energies");
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+}
+
+void Scorer::enable_timing(bool on) { timing_ = on; }
+
+void Scorer::pair_kernel_time(double *total_ms, uint64_t *launches) {
+    double ms = timed_ms_;
+    uint64_t n = timed_launches_;
+    for (size_t i = 0; i < events_used_; i++) {
+        hip_check(hipEventSynchronize(events_[i].second), "hipEventSynchronize");
+        float t = 0.f;
+        hip_check(hipEventElapsedTime(&t, events_[i].first, events_[i].second), "hipEventElapsedTime");
+        ms += t;
+        n++;
+    }
+    events_used_ = 0;
+    timed_ms_ = 0.0;
+    timed_launches_ = 0;
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+}
+
+void Scorer::kernel_info(ld_kernel_info *out) const {
+    out->pair_kernel_name = pair_kernel_name(method_);
+    out->block_threads = kBlockThreads;
+    out->receptor_chunks = (uint32_t)pair_.n_chunks;
+    out->lds_bytes = (uint32_t)pair_kernel_lds_bytes(pair_);
+    out->pair_tests_per_pose = (uint64_t)pair_.rec.n * (uint64_t)pair_.lig.n;
+    // DFIRE 26 B/atom (3 f64 + u16 type), DNA 48 B/atom (6 f64), + 240 B/atom
+    // per ANM-deformed molecule (10 modes x 24 B), + 56 B pose in + 8 B energy out.
+    const uint64_t atoms = (uint64_t)pair_.rec.n + (uint64_t)pair_.lig.n;
+    uint64_t bytes = (method_ == LD_METHOD_DFIRE ? 26 : 48) * atoms + 64;
+    if (use_anm_) bytes += 24ull * pair_.rec.num_anm * pair_.rec.n + 24ull * pair_.lig.num_anm * pair_.lig.n;
+    out->stream_bytes_per_pose = bytes;
+}
+
+}  // namespace ld

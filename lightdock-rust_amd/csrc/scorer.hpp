@@ -1,0 +1,119 @@
+// scorer.hpp -- the object behind an `ld_scorer*`: device-resident docking models + the
+// workspace of the pose-energy kernels.  Plays the role of the reference's
+// `Box<dyn Score>` (DFIRE / DNA structs, src/dfire.rs:193-198, src/dna.rs:367-372).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "host/error.hpp"
+#include "kernels/pose_energy.hpp"
+#include "lightdock_hip.h"
+
+namespace ld {
+
+inline void hip_check(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw Error(LD_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// Owns a set of device allocations; freed together.
+class DeviceArena {
+   public:
+    ~DeviceArena();
+    template <typename T>
+    T *upload(const std::vector<T> &host, size_t min_count = 0) {
+        size_t count = host.size() > min_count ? host.size() : min_count;
+        if (count == 0) count = 1;
+        T *d = static_cast<T *>(alloc_bytes(count * sizeof(T)));
+        hip_check(hipMemset(d, 0, count * sizeof(T)), "hipMemset");
+        if (!host.empty()) hip_check(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D");
+        return d;
+    }
+    void *alloc_bytes(size_t bytes);
+
+   private:
+    std::vector<void *> blocks_;
+};
+
+// A grow-only device buffer.
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    void reserve(size_t want);
+    void release();
+};
+
+struct HostMolecule {  // what ld_scorer_model_arrays hands back
+    std::vector<double> coordinates;
+    std::vector<uint32_t> dfire_types;
+    std::vector<double> ele_charges, vdw_charges, vdw_radii;
+};
+
+// DFIRE's distance binning as a lookup over cells of 0.25 A^2 (DESIGN.md "bin LUT").
+int dfire_bin_reference(double dist2);               // the formula, src/dfire.rs:49-53,336-337
+struct DfireBinning {
+    std::vector<uint8_t> lut;   // kDfireLutCells: bin at the lower edge of each 0.25 A^2 cell
+    std::vector<double> step;   // kDfireSteps: step[b] = first d2 the reference puts in bin >= b
+};
+DfireBinning build_dfire_binning();                  // throws if the self-check fails
+double dfire_interface_d2();                         // largest d2 with sqrt(d2)*2-1 <= 3.9
+
+class Scorer {
+   public:
+    explicit Scorer(const ld_scorer_desc &desc);
+    ~Scorer();
+    Scorer(const Scorer &) = delete;
+    Scorer &operator=(const Scorer &) = delete;
+
+    int method() const { return method_; }
+    bool use_anm() const { return use_anm_; }
+    size_t anm_rec() const { return use_anm_ ? (size_t)pair_.rec.num_anm : 0; }
+    size_t anm_lig() const { return use_anm_ ? (size_t)pair_.lig.num_anm : 0; }
+    size_t pose_len() const { return 7 + anm_rec() + anm_lig(); }
+    size_t num_atoms(int side) const { return side ? (size_t)pair_.lig.n : (size_t)pair_.rec.n; }
+    const HostMolecule &host_molecule(int side) const { return side ? host_lig_ : host_rec_; }
+    int device() const { return device_; }
+    hipStream_t stream() const { return stream_; }
+    void set_stream(hipStream_t s) { stream_ = s; }
+
+    // Enqueue K1 for n poses already in HBM.  active / pair_counts may be null.
+    void energy_batch_device(size_t n, const double *d_poses, size_t stride, const uint8_t *d_active,
+                             double *d_energies, uint32_t *d_pair_counts);
+    // Host-pointer convenience: H2D, kernels, D2H, synchronise.
+    void energy_batch_host(size_t n, const double *poses, size_t stride, double *energies);
+
+    void kernel_info(ld_kernel_info *out) const;
+    void enable_timing(bool on);
+    void pair_kernel_time(double *total_ms, uint64_t *launches);
+
+   private:
+    void upload_molecule(const ld_molecule &m, bool is_receptor, DeviceMolecule &dev, HostMolecule &host,
+                         std::vector<uint32_t> &group_offsets, std::vector<uint32_t> &group_slots,
+                         std::vector<uint32_t> &membrane_slots);
+    void reserve_workspace(size_t n_poses, bool counts);
+
+    int device_ = 0;
+    hipStream_t stream_ = nullptr;
+    int method_ = 0;
+    bool use_anm_ = false;
+    DeviceArena arena_;
+    PairLaunch pair_;     // receptor / ligand / table pointers filled once; batch fields per call
+    TailTables tail_;
+    HostMolecule host_rec_, host_lig_;
+    DeviceBuffer ws_partial_, ws_flags_, ws_counts_, ws_poses_, ws_energies_;
+    bool timing_ = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events_;  // pool, reused
+    size_t events_used_ = 0;
+    double timed_ms_ = 0.0;
+    uint64_t timed_launches_ = 0;
+};
+
+}  // namespace ld
+
+struct ld_scorer {
+    ld::Scorer impl;
+    explicit ld_scorer(const ld_scorer_desc &d) : impl(d) {}
+};

@@ -1,0 +1,201 @@
+"""Host-side checks that run without a GPU: the C-ABI library loads and exports what
+include/lightdock_hip.h declares, the host model builder agrees with the oracle, and the
+product fails loudly (no CPU fallback) when no HIP device is present."""
+import math
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import CASES, GOLDEN, case_paths
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load_library()
+    header = open(os.path.join(pkg.INCLUDE_DIR, "lightdock_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    names = set(re.findall(r"\b(ld_[a-z0-9_]+)\s*\(", header))
+    assert len(names) >= 30
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, "declared but not exported: %s" % missing
+    assert b"gfx950" in lib.ld_version()
+
+
+def test_no_torch_types_in_the_abi(pkg):
+    header = open(os.path.join(pkg.INCLUDE_DIR, "lightdock_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)   # comments may mention torch tensors
+    assert "torch" not in header and "at::" not in header and "std::" not in header
+
+
+@pytest.mark.parametrize("name", ["1ppe", "1k4c", "2uuy", "1azp"])
+def test_host_model_builder_matches_oracle(pkg, orc, table, name):
+    c, d, rec, lig = case_paths(name)
+    from conftest import case_kwargs
+    method, rec, lig, kw = case_kwargs(name, orc, table)
+    o = orc.Scorer(method, rec, lig, **kw)
+    for side, path, active in ((0, rec, c.get("rec_active", [])), (1, lig, c.get("lig_active", []))):
+        m = pkg.model_from_pdb(method, path, active=active)
+        w = o.model(side)
+        assert np.array_equal(m["coordinates"], w["coordinates"])
+        for k in ("dfire_types", "ele_charges", "vdw_charges", "vdw_radii"):
+            if k in w:
+                assert np.array_equal(m[k], w[k]), k
+        assert np.array_equal(m["membrane"], w["membrane"])
+        assert np.array_equal(m["restraint_offsets"], w["restraint_offsets"])
+        assert np.array_equal(m["restraint_atoms"], w["restraint_atoms"])
+
+
+def test_pdb_walk_order_groups_like_pdbtbx(pkg, orc, table, tmp_path):
+    """Atoms of one residue that are split in the file, and a chain that re-appears, are
+    regrouped chain -> residue -> atom (first-appearance order), by both implementations."""
+    lines = [
+        "ATOM      1  N   ALA A   1       0.000   0.000   0.000  1.00  0.00           N",
+        "ATOM      2  N   GLY B   1       5.000   0.000   0.000  1.00  0.00           N",
+        "ATOM      3  CA  ALA A   1       1.000   0.000   0.000  1.00  0.00           C",
+        "ATOM      4  N   SER A   2       2.000   0.000   0.000  1.00  0.00           N",
+        "ATOM      5  C   ALA A   1       3.000   0.000   0.000  1.00  0.00           C",
+        "ATOM      6  N   SER A   2A      4.000   0.000   0.000  1.00  0.00           N",
+    ]
+    p = tmp_path / "mix.pdb"
+    p.write_text("\n".join(lines) + "\n")
+    m = pkg.model_from_pdb("dfire", str(p), active=["A.SER.2A", "A.ALA.1"])
+    assert list(m["coordinates"][:, 0]) == [0.0, 1.0, 3.0, 2.0, 4.0, 5.0]
+    assert list(m["dfire_types"]) == [74, 75, 76, 90, 90, 79]
+    assert list(m["restraint_offsets"]) == [0, 3, 4] and list(m["restraint_atoms"]) == [0, 1, 2, 4]
+    good = os.path.join(GOLDEN, "1ppe", "lightdock_1ppe_i.pdb")
+    o = orc.Scorer("dfire", str(p), good, rec_active=["A.SER.2A", "A.ALA.1"], potential=table)
+    w = o.model(0)
+    assert np.array_equal(w["coordinates"], m["coordinates"]) and np.array_equal(w["dfire_types"], m["dfire_types"])
+    assert np.array_equal(w["restraint_atoms"], m["restraint_atoms"])
+
+
+def test_host_unsupported_atoms_fail_with_reference_messages(pkg, tmp_path):
+    bad = tmp_path / "bad.pdb"
+    bad.write_text("ATOM      1  N   XYZ A   1      11.104  13.207   2.100  1.00  0.00           N\n")
+    with pytest.raises(pkg.LightdockError, match="Residue name not supported in DFIRE"):
+        pkg.model_from_pdb("dfire", str(bad))
+    bad.write_text("ATOM      1  H1  ALA A   1      11.104  13.207   2.100  1.00  0.00           H\n")
+    with pytest.raises(pkg.LightdockError, match="Not supported atom type"):
+        pkg.model_from_pdb("dfire", str(bad))
+    m = pkg.model_from_pdb("dna", str(bad))      # DNA: N-terminal H1 falls back to "ALA-H" (src/dna.rs:321-326)
+    assert m["ele_charges"][0] == 0.2719 and m["vdw_radii"][0] == 0.6
+    bad.write_text("ATOM      1  QQ  ALA A   1      11.104  13.207   2.100  1.00  0.00           H\n")
+    with pytest.raises(pkg.LightdockError, match=r"DNA Error: Atom \[\"ALA-QQ\"\] not supported"):
+        pkg.model_from_pdb("dna", str(bad))
+    with pytest.raises(pkg.LightdockError, match="cannot open PDB"):
+        pkg.model_from_pdb("dna", str(tmp_path / "missing.pdb"))
+
+
+def test_dfire_bin_lut_equals_reference_formula(pkg, orc):
+    """The kernel's sqrt-free binning must equal DIST_TO_BINS[(sqrt(d2)*2-1) as usize]-1
+    (src/dfire.rs:336-337) for EVERY double in [0, 225].  Both sides are monotone step functions
+    of d2, so agreement at both ends of each 0.25-wide cell plus on each exact step proves it."""
+    lut, steps, iface = pkg.dfire_bin_lut()
+    steps = np.append(steps, np.inf)
+
+    def kernel_bin(d2):
+        b = int(lut[int(d2 * 4.0)])
+        return b + (1 if d2 >= steps[b + 1] else 0)
+
+    assert kernel_bin(0.0) == 0 and kernel_bin(225.0) == 20 and kernel_bin(math.nextafter(225.0, 0)) == 19
+    rounding_cases = 0
+    for c in range(0, 900):
+        lo, hi = c * 0.25, math.nextafter((c + 1) * 0.25, 0.0)
+        assert orc.dfire_bin(lo) == kernel_bin(lo)
+        assert orc.dfire_bin(hi) == kernel_bin(hi)
+        rounding_cases += orc.dfire_bin(hi) != lut[c]
+    assert rounding_cases > 0     # e.g. sqrt(pred(6.25)) rounds up to 2.5: a plain cell LUT would be wrong
+    for b in range(1, 21):
+        assert orc.dfire_bin(steps[b]) == b and orc.dfire_bin(math.nextafter(steps[b], 0.0)) == b - 1
+    rng = np.random.default_rng(5)
+    for d2 in rng.uniform(0.0, 225.0, size=20000):
+        assert orc.dfire_bin(d2) == kernel_bin(d2)
+    # interface threshold: d <= 3.9 (src/dfire.rs:339) as a d2 threshold
+    assert math.sqrt(iface) * 2.0 - 1.0 <= 3.9 < math.sqrt(math.nextafter(iface, 1e9)) * 2.0 - 1.0
+    assert abs(iface - 2.45 ** 2) < 1e-12
+
+
+def test_stdrng_key_matches_oracle_stream(pkg, orc):
+    """Host key expansion (PCG32) feeds the device ChaCha20; check it through the oracle's
+    generator by re-deriving the first block in numpy."""
+    key = pkg.stdrng_key(324324)
+
+    def chacha_block(key, counter):
+        def rotl(v, n):
+            return ((v << n) & 0xffffffff) | (v >> (32 - n))
+        s = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + [int(k) for k in key] + \
+            [counter & 0xffffffff, counter >> 32, 0, 0]
+        x = list(s)
+
+        def qr(a, b, c, d):
+            x[a] = (x[a] + x[b]) & 0xffffffff; x[d] = rotl(x[d] ^ x[a], 16)
+            x[c] = (x[c] + x[d]) & 0xffffffff; x[b] = rotl(x[b] ^ x[c], 12)
+            x[a] = (x[a] + x[b]) & 0xffffffff; x[d] = rotl(x[d] ^ x[a], 8)
+            x[c] = (x[c] + x[d]) & 0xffffffff; x[b] = rotl(x[b] ^ x[c], 7)
+        for _ in range(10):
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+        return [(a + b) & 0xffffffff for a, b in zip(x, s)]
+
+    r = orc.Rng(324324)
+    for blk in range(3):
+        w = chacha_block(key, blk)
+        for k in range(8):
+            assert r.next_u64() == (w[2 * k + 1] << 32) | w[2 * k]
+
+
+def test_synthetic_dcparams_format(pkg, orc, tmp_path):
+    t = pkg.synth.dcparams()
+    assert t.shape == (169 * 169 * 20,) and np.all(t[0::20] == 10.0)
+    assert np.all(np.abs(np.delete(t, np.s_[0::20])) <= 2.0)
+    p = tmp_path / "DCparams"
+    pkg.synth.write_dcparams(str(p), t)
+    assert np.array_equal(orc.load_dcparams(str(p)), t)      # text round trip is exact
+    assert np.array_equal(pkg.load_dcparams(str(p)), t)
+    with pytest.raises(pkg.LightdockError, match="DFIRE parameters"):
+        short = tmp_path / "short"
+        short.write_text("1.0\n2.0\n")
+        pkg.load_dcparams(str(short))
+
+
+def test_cli_usage_errors_match_reference(pkg, tmp_path):
+    """src/bin/lightdock-rust.rs:101,112,121,142: message on stderr, exit status 0; these paths
+    return before any GPU work."""
+    cli = pkg.CLI_PATH
+    r = subprocess.run([cli], capture_output=True, text=True)
+    assert r.returncode == 0 and "Wrong command line. Usage:" in r.stderr
+    r = subprocess.run([cli, "a", "b", "ten", "dfire"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stderr.strip() == "Error: steps argument must be a number"
+    r = subprocess.run([cli, "a", "b", "10", "zrank"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stderr.strip() == "Error: method not supported"
+    r = subprocess.run([cli, "nope.json", "initial_positions_0.dat", "1", "DNA"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and r.stderr.startswith('Error reading setup file ["nope.json"]')
+    bad = tmp_path / "setup.json"
+    bad.write_text('{"anm_seed": 1}')
+    r = subprocess.run([cli, str(bad), "initial_positions_0.dat", "1", "dna"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and "missing field" in r.stderr
+    # a swarm file name without an id is a panic in the reference (exit 101)
+    good = os.path.join(GOLDEN, "1ppe", "setup.json")
+    r = subprocess.run([cli, good, "positions.dat", "1", "dna"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 101 and "Could not parse swarm from swarm filename" in r.stderr
+
+
+def test_product_has_no_cpu_fallback(pkg, table):
+    """Without a HIP device the scorer must refuse to exist (never route through the oracle)."""
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    c, d, rec, lig = case_paths("1ppe")
+    with pytest.raises(pkg.LightdockError, match="no HIP device|no CPU fallback"):
+        pkg.Scorer.from_pdb("dfire", rec, lig, potential=table)
+    src = []
+    root = os.path.dirname(pkg.__file__)
+    for dirpath, _, files in os.walk(root):
+        if "build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                src.append(open(os.path.join(dirpath, f), errors="ignore").read())
+    blob = "\n".join(src)
+    assert "ld_oracle" not in blob and "oracle/" not in blob.replace("no oracle/_ref", "")

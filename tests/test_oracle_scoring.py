@@ -1,0 +1,121 @@
+"""Oracle vs the reference's scorer known-answer tests and committed example outputs."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, case_kwargs, case_positions, parse_gso
+
+
+def test_dna_1azp_known_answer(orc):
+    """src/dna.rs:538-572: identity pose of tests/1azp -> -364.88126358158974, assert_eq!."""
+    d = os.path.join(GOLDEN, "unit", "1azp")
+    s = orc.Scorer("dna", os.path.join(d, "1azp_receptor.pdb"), os.path.join(d, "1azp_ligand.pdb"))
+    assert s.num_atoms(0) == 1094 and s.num_atoms(1) == 506
+    assert s.energy([0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]) == -364.88126358158974
+
+
+def test_dna_gso1_energies_1azp(orc, table):
+    """gso_1.out = the 200 starting poses with their energies (nobody moves at step 1)."""
+    method, rec, lig, kw = case_kwargs("1azp", orc, table)
+    s = orc.Scorer(method, rec, lig, **kw)
+    poses = case_positions("1azp", orc)
+    _, _, nn, vis, sco = parse_gso(os.path.join(GOLDEN, "1azp", "swarm_0", "gso_1.out"))
+    got = s.energy_rows(poses[:40])
+    assert np.all(np.abs(got - sco[:40]) <= 0.5000001e-8 + 1e-12 * np.abs(sco[:40]))
+    assert np.all(nn == 0) and np.allclose(vis, 0.6)
+
+
+@pytest.mark.timeout(600)
+def test_gso_replay_1azp_files_identical(orc, tmp_path):
+    """The oracle CLI reproduces the committed example/1azp/swarm_0/gso_{1,10,20}.out byte for byte
+    (DNA + ANM + restraints + StdRng + GSO + output format).  20 steps keep the CPU suite short;
+    the 100-step replay is also byte-identical."""
+    src = os.path.join(GOLDEN, "1azp")
+    for f in ("rec_nm.npy", "lig_nm.npy"):
+        shutil.copy(os.path.join(src, f), tmp_path)
+    orc.lib()
+    r = subprocess.run([orc.CLI_PATH, os.path.join(src, "setup.json"), os.path.join(src, "initial_positions_0.dat"),
+                        "20", "dna"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Creating GSO with 200 glowworms" in r.stdout and "Starting optimization (20 steps)" in r.stdout
+    for step in (1, 10, 20):
+        want = open(os.path.join(src, "swarm_0", "gso_%d.out" % step), "rb").read()
+        got = open(os.path.join(tmp_path, "swarm_0", "gso_%d.out" % step), "rb").read()
+        assert got == want, "gso_%d.out differs" % step
+
+
+def test_cli_usage_errors_exit_zero(orc, tmp_path):
+    """src/bin/lightdock-rust.rs:101,112,142: usage errors go to stderr, exit status 0."""
+    orc.lib()
+    r = subprocess.run([orc.CLI_PATH], capture_output=True, text=True)
+    assert r.returncode == 0 and "Wrong command line" in r.stderr
+    r = subprocess.run([orc.CLI_PATH, "a", "b", "x", "dfire"], capture_output=True, text=True)
+    assert r.returncode == 0 and "steps argument must be a number" in r.stderr
+    r = subprocess.run([orc.CLI_PATH, "a", "b", "1", "zrank"], capture_output=True, text=True)
+    assert r.returncode == 0 and "method not supported" in r.stderr
+    r = subprocess.run([orc.CLI_PATH, "nope.json", "initial_positions_0.dat", "1", "dna"], capture_output=True, text=True,
+                       cwd=tmp_path)
+    assert r.returncode == 0 and "Error reading setup file" in r.stderr
+
+
+def test_dfire_bins_follow_dist_to_bins(orc):
+    """src/dfire.rs:49-53,336-337 incl. the r = 15.0 A corner that reads bin 20."""
+    assert orc.dfire_bin(0.0) == 0 and orc.dfire_bin(0.09 ** 2) == 0      # negative d saturates to index 0
+    assert orc.dfire_bin(1.99 ** 2) == 0 and orc.dfire_bin(2.0 ** 2) == 1
+    assert orc.dfire_bin(7.99 ** 2) == 12 and orc.dfire_bin(8.0 ** 2) == 13
+    assert orc.dfire_bin(14.99 ** 2) == 19 and orc.dfire_bin(225.0) == 20
+
+
+def test_dfire_typing_of_fixtures(orc, table):
+    """Every atom of the DFIRE fixtures maps to a type 0..167; 1k4c's 453 MMB beads are type 167."""
+    for name, n_rec, n_lig in (("1ppe", 1615, 221), ("1k4c", 3413, 3268), ("2uuy", None, None)):
+        method, rec, lig, kw = case_kwargs(name, orc, table)
+        s = orc.Scorer(method, rec, lig, **kw)
+        if n_rec:
+            assert (s.num_atoms(0), s.num_atoms(1)) == (n_rec, n_lig)
+        for side in (0, 1):
+            m = s.model(side)
+            assert m["dfire_types"].max() <= 167
+        if name == "1k4c":
+            m = s.model(0)
+            assert len(m["membrane"]) == 453 and np.all(m["dfire_types"][m["membrane"]] == 167)
+        if name == "1ppe":
+            m = s.model(0)
+            assert len(m["restraint_offsets"]) == 2 and m["restraint_offsets"][1] == 8   # E.ILE.16: 8 heavy atoms
+
+
+def test_dfire_synthetic_table_energy_is_deterministic(orc, table):
+    method, rec, lig, kw = case_kwargs("1ppe", orc, table)
+    s = orc.Scorer(method, rec, lig, **kw)
+    poses = case_positions("1ppe", orc)
+    e, stats = s.energy_ex_row(poses[0])
+    assert e == s.energy_row(poses[0])
+    assert 20000 < stats[5] < 45000            # in-cutoff pairs of a starting pose (mean 31 299)
+    raw = stats[0]
+    score = (raw * 0.0157 - 4.7) * -1.0
+    assert e == score + stats[2] * score + stats[3] * score
+
+
+def test_unsupported_atoms_are_errors(orc, table, tmp_path):
+    """src/dfire.rs:43,180 panics -> constructor errors."""
+    bad = tmp_path / "bad.pdb"
+    bad.write_text("ATOM      1  N   XYZ A   1      11.104  13.207   2.100  1.00  0.00           N\n")
+    good = os.path.join(GOLDEN, "1ppe", "lightdock_1ppe_i.pdb")
+    with pytest.raises(RuntimeError, match="Residue name not supported"):
+        orc.Scorer("dfire", str(bad), good, potential=table)
+    bad.write_text("ATOM      1  H1  ALA A   1      11.104  13.207   2.100  1.00  0.00           H\n")
+    with pytest.raises(RuntimeError, match="Not supported atom type"):
+        orc.Scorer("dfire", str(bad), good, potential=table)
+
+
+def test_real_dcparams_goldens(orc, real_dcparams):
+    """Opt-in: with the real table the oracle must hit src/dfire.rs:415 and the leaked values
+    of src/dfire.rs:370-380."""
+    t = orc.load_dcparams(real_dcparams)
+    assert t[0] == 10.0 and t[2] == -0.624030868 and t[4998] == -0.0458685914 and t[168 * 168 * 20 - 1] == 0.0
+    d = os.path.join(GOLDEN, "unit", "2oob")
+    s = orc.Scorer("dfire", os.path.join(d, "2oob_receptor.pdb"), os.path.join(d, "2oob_ligand.pdb"), potential=t)
+    assert s.energy([0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]) == 16.7540569503498
