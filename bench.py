@@ -171,7 +171,7 @@ def main():
                          "pair_tests_per_s": info["pair_tests_per_pose"] * args.batch / kern_s},
         }
         if args.cpu_seconds > 0:
-            threads = os.cpu_count() or 1
+            threads = min(len(os.sched_getaffinity(0)), 64)
             cb, cpu_e = cpu_baseline(case, table, poses, args.cpu_seconds, threads)
             out["cpu_baseline"] = cb
             n = len(cpu_e)

@@ -27,6 +27,15 @@ def orc():
 def pkg():
     """The product package, lightdock-rust_amd/ (C ABI via ctypes)."""
     import __graft_entry__ as ge
+    # torch bundles its own HIP runtime; when both live in one process torch has to come up
+    # first or it finds "No HIP GPUs".  Only matters for the GPU tests that borrow torch for
+    # device buffers; the product itself never imports torch.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     return ge.package()
 
 
