@@ -6,6 +6,8 @@
 #include <cstring>
 #include <limits>
 
+#include "host/spatial_order.hpp"
+
 namespace ld {
 
 // ---------------------------------------------------------------------------------------
@@ -208,6 +210,7 @@ void Scorer::upload_molecule(const ld_molecule &m, bool is_receptor, DeviceMolec
     for (size_t k = 0; k < m.n_membrane; k++) membrane_slots.push_back(slot_of(m.membrane[k]));
     dev.slot = arena_.upload(slot);
     dev.flag_words = (int)((next + 31) / 32);
+    (is_receptor ? host_slot_rec_ : host_slot_lig_).assign(slot.begin(), slot.begin() + (long)n);
 
     dev.num_anm = 0;
     dev.modes = nullptr;
@@ -279,6 +282,114 @@ Scorer::Scorer(const ld_scorer_desc &desc) {
     pair_.chunk_atoms = (pair_.rec.n + pair_.n_chunks - 1) / pair_.n_chunks;
     const int n_groups = (pair_.lig.n + 63) / 64;
     pair_.split_j = (n_groups % kWaves != 0 && n_groups < 4 * kWaves) ? 1 : 0;
+
+    if (method_ == LD_METHOD_DFIRE) {
+        const char *k = std::getenv("LIGHTDOCK_DFIRE_KERNEL");
+        use_tiled_ = !(k && std::strcmp(k, "allpairs") == 0);
+        if (use_tiled_) build_tiled(desc);
+    }
+}
+
+void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, const DeviceMolecule &plain, TiledMolecule &out) {
+    const size_t n = m.n_atoms;
+    const std::vector<uint32_t> order = spatial_tile_order(m.coordinates, n);
+    const size_t np = order.size();
+    const uint32_t kPad = std::numeric_limits<uint32_t>::max();
+    // padding atoms: receptor at -1e30, ligand at +1e30 (the kernel re-places ligand padding
+    // after posing), so that no padding/padding pair can ever look close
+    std::vector<double> x(np, is_receptor ? -1.0e30 : 1.0e30), y(np, 0.0), z(np, 0.0);
+    std::vector<uint32_t> t(np, 0);
+    std::vector<int32_t> slot(np, -1);
+    const std::vector<int32_t> &hslot = is_receptor ? host_slot_rec_ : host_slot_lig_;
+    for (size_t i = 0; i < np; i++) {
+        const uint32_t a = order[i];
+        if (a == kPad) {
+            if (i < n) throw Error(LD_ERR_INVALID, "spatial order: padding before the tail");
+            continue;
+        }
+        x[i] = m.coordinates[3 * (size_t)a];
+        y[i] = m.coordinates[3 * (size_t)a + 1];
+        z[i] = m.coordinates[3 * (size_t)a + 2];
+        t[i] = m.dfire_types[a] * (is_receptor ? kDfireRowStride : 20u);
+        slot[i] = hslot[a];
+    }
+    out.n_real = (int)n;
+    out.n_tiles = (int)(np / 64);
+    out.x = arena_.upload(x);
+    out.y = arena_.upload(y);
+    out.z = arena_.upload(z);
+    out.tindex = arena_.upload(t);
+    out.slot = arena_.upload(slot);
+    out.flag_words = plain.flag_words;
+    out.num_anm = 0;
+    out.modes = nullptr;
+    if (use_anm_ && m.num_anm > 0) {
+        std::vector<double> modes(m.num_anm * 3 * np, 0.0);
+        for (size_t k = 0; k < m.num_anm; k++)
+            for (size_t i = 0; i < np; i++) {
+                if (order[i] == kPad) continue;
+                for (int c = 0; c < 3; c++) modes[(k * 3 + c) * np + i] = m.nmodes[k * n * 3 + (size_t)order[i] * 3 + c];
+            }
+        out.modes = arena_.upload(modes);
+        out.num_anm = (int)m.num_anm;
+    }
+}
+
+void Scorer::build_tiled(const ld_scorer_desc &desc) {
+    hip_check(configure_dfire_tiled(), "hipFuncSetAttribute(dynamic LDS)");
+    upload_tiled_molecule(desc.receptor, true, pair_.rec, tiled_.rec);
+    upload_tiled_molecule(desc.ligand, false, pair_.lig, tiled_.lig);
+    tiled_.use_anm = use_anm_ ? 1 : 0;
+    tiled_.table = pair_.table;
+    tiled_.bin_step = pair_.bin_step;
+    tiled_.iface_d2 = pair_.iface_d2;
+    {   // cell code = bin at the cell's lower edge | 0x80 when a bin step falls inside the cell
+        const DfireBinning b = build_dfire_binning();
+        std::vector<uint8_t> code(b.lut);
+        for (int c = 0; c <= 900; c++) {
+            const int bin = b.lut[c];
+            if (b.step[bin + 1] < (c + 1) * 0.25) code[c] |= 0x80u;
+        }
+        tiled_.lut = arena_.upload(code);
+    }
+    // Work split.  items = ligand tiles x receptor-tile ranges, dealt round-robin to W waves;
+    // every item re-poses its ligand tile, so ranges cost a little.  Minimise
+    // ceil(items / W) * (c_pose + c_pairs / S), c_pose : c_pairs ~ 0.08, prefer more waves.
+    const int n_lt = tiled_.lig.n_tiles, nt = tiled_.rec.n_tiles;
+    int best_w = 16, best_s = 1;
+    double best_cost = 1e300;
+    for (int w = 16; w >= 8; w--) {
+        const int fit = tiled_max_chunk_tiles(w);
+        const int chunks = (nt + fit - 1) / fit;
+        const int ct = (nt + chunks - 1) / chunks;
+        for (int s = 1; s <= 4 && s <= ct; s++) {
+            const int items = n_lt * s;
+            const double cost = chunks * ((items + w - 1) / w) * (0.08 + 1.0 / s);
+            if (cost < best_cost - 1e-12) {
+                best_cost = cost;
+                best_w = w;
+                best_s = s;
+            }
+        }
+    }
+    if (const char *e = std::getenv("LIGHTDOCK_TILED_WAVES")) {
+        int v = std::atoi(e);
+        if (v >= 1 && v <= kTiledMaxWaves) best_w = v;
+    }
+    if (const char *e = std::getenv("LIGHTDOCK_TILED_SEGMENTS")) {
+        int v = std::atoi(e);
+        if (v >= 1 && v <= 8) best_s = v;
+    }
+    tiled_.waves = best_w;
+    tiled_.segments = best_s;
+    int fit = tiled_max_chunk_tiles(best_w);
+    if (const char *e = std::getenv("LIGHTDOCK_TILED_CHUNK_TILES")) {
+        int v = std::atoi(e);
+        if (v >= 1 && v <= fit) fit = v;
+    }
+    tiled_.n_chunks = (nt + fit - 1) / fit;
+    tiled_.chunk_tiles = (nt + tiled_.n_chunks - 1) / tiled_.n_chunks;
+    if (tiled_.segments > tiled_.chunk_tiles) tiled_.segments = tiled_.chunk_tiles;
 }
 
 Scorer::~Scorer() {
@@ -289,15 +400,20 @@ Scorer::~Scorer() {
     ws_partial_.release();
     ws_flags_.release();
     ws_counts_.release();
+    ws_tested_.release();
     ws_poses_.release();
     ws_energies_.release();
 }
 
 void Scorer::reserve_workspace(size_t n_poses, bool counts) {
     const size_t words = (size_t)(pair_.rec.flag_words + pair_.lig.flag_words);
-    ws_partial_.reserve(n_poses * pair_.n_chunks * 2 * sizeof(double));
+    const size_t chunks = (size_t)std::max(pair_.n_chunks, use_tiled_ ? tiled_.n_chunks : 0);
+    ws_partial_.reserve(n_poses * chunks * 2 * sizeof(double));
     ws_flags_.reserve(std::max<size_t>(n_poses * words * sizeof(uint32_t), 16));
-    if (counts) ws_counts_.reserve(n_poses * pair_.n_chunks * sizeof(uint32_t));
+    if (counts) {
+        ws_counts_.reserve(n_poses * chunks * sizeof(uint32_t));
+        ws_tested_.reserve(n_poses * chunks * sizeof(uint32_t));
+    }
 }
 
 void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride, const uint8_t *d_active,
@@ -335,7 +451,21 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
         }
         hip_check(hipEventRecord(events_[events_used_].first, stream_), "hipEventRecord");
     }
-    hip_check(launch_pair_kernel(p, stream_), "launch pose_energy_pairs");
+    if (use_tiled_) {
+        TiledLaunch t = tiled_;
+        t.poses = d_poses;
+        t.stride = stride;
+        t.active = d_active;
+        t.n_poses = n;
+        t.partial = p.partial;
+        t.flags = p.flags;
+        t.count_partial = p.count_partial;
+        t.tested_partial = p.count_partial ? static_cast<uint32_t *>(ws_tested_.ptr) : nullptr;
+        p.n_chunks = t.n_chunks;  // the tail kernel folds this many partials
+        hip_check(launch_dfire_tiled(t, stream_), "launch dfire_tiled_pairs");
+    } else {
+        hip_check(launch_pair_kernel(p, stream_), "launch pose_energy_pairs");
+    }
     if (timing_) {
         hip_check(hipEventRecord(events_[events_used_].second, stream_), "hipEventRecord");
         events_used_++;
@@ -389,10 +519,10 @@ void Scorer::pair_kernel_time(double *total_ms, uint64_t *launches) {
 }
 
 void Scorer::kernel_info(ld_kernel_info *out) const {
-    out->pair_kernel_name = pair_kernel_name(method_);
-    out->block_threads = kBlockThreads;
-    out->receptor_chunks = (uint32_t)pair_.n_chunks;
-    out->lds_bytes = (uint32_t)pair_kernel_lds_bytes(pair_);
+    out->pair_kernel_name = use_tiled_ ? "dfire_tiled_pairs" : pair_kernel_name(method_);
+    out->block_threads = use_tiled_ ? (uint32_t)tiled_.waves * 64 : (uint32_t)kBlockThreads;
+    out->receptor_chunks = (uint32_t)(use_tiled_ ? tiled_.n_chunks : pair_.n_chunks);
+    out->lds_bytes = (uint32_t)(use_tiled_ ? tiled_kernel_lds_bytes(tiled_) : pair_kernel_lds_bytes(pair_));
     out->pair_tests_per_pose = (uint64_t)pair_.rec.n * (uint64_t)pair_.lig.n;
     // DFIRE 26 B/atom (3 f64 + u16 type), DNA 48 B/atom (6 f64), + 240 B/atom
     // per ANM-deformed molecule (10 modes x 24 B), + 56 B pose in + 8 B energy out.

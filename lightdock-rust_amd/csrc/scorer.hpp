@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "host/error.hpp"
+#include "kernels/dfire_tiled.hpp"
 #include "kernels/pose_energy.hpp"
 #include "lightdock_hip.h"
 
@@ -86,6 +87,8 @@ class Scorer {
     void energy_batch_host(size_t n, const double *poses, size_t stride, double *energies);
 
     void kernel_info(ld_kernel_info *out) const;
+    // diagnostics of the last counting launch: 8x8 atom-pair blocks evaluated per pose (tiled kernel)
+    const uint32_t *tested_blocks_device() const { return static_cast<const uint32_t *>(ws_tested_.ptr); }
     void enable_timing(bool on);
     void pair_kernel_time(double *total_ms, uint64_t *launches);
 
@@ -94,6 +97,8 @@ class Scorer {
                          std::vector<uint32_t> &group_offsets, std::vector<uint32_t> &group_slots,
                          std::vector<uint32_t> &membrane_slots);
     void reserve_workspace(size_t n_poses, bool counts);
+    void build_tiled(const ld_scorer_desc &desc);
+    void upload_tiled_molecule(const ld_molecule &m, bool is_receptor, const DeviceMolecule &plain, TiledMolecule &out);
 
     int device_ = 0;
     hipStream_t stream_ = nullptr;
@@ -102,8 +107,11 @@ class Scorer {
     DeviceArena arena_;
     PairLaunch pair_;     // receptor / ligand / table pointers filled once; batch fields per call
     TailTables tail_;
+    bool use_tiled_ = false;  // DFIRE: bounding-box culled kernel (default) instead of all-pairs
+    TiledLaunch tiled_;
+    std::vector<int32_t> host_slot_rec_, host_slot_lig_;  // per original atom, as uploaded to the all-pairs path
     HostMolecule host_rec_, host_lig_;
-    DeviceBuffer ws_partial_, ws_flags_, ws_counts_, ws_poses_, ws_energies_;
+    DeviceBuffer ws_partial_, ws_flags_, ws_counts_, ws_tested_, ws_poses_, ws_energies_;
     bool timing_ = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events_;  // pool, reused
     size_t events_used_ = 0;

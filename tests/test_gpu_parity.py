@@ -298,3 +298,43 @@ def test_real_dcparams_goldens_on_gpu(pkg, orc, real_dcparams):
     d = os.path.join(GOLDEN, "unit", "2oob")
     s = pkg.Scorer.from_pdb("dfire", os.path.join(d, "2oob_receptor.pdb"), os.path.join(d, "2oob_ligand.pdb"), potential=t)
     assert abs(s.energy([0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]) - 16.7540569503498) < 1e-11
+
+
+@pytest.mark.parametrize("env", [
+    {"LIGHTDOCK_DFIRE_KERNEL": "allpairs"},
+    {"LIGHTDOCK_TILED_CHUNK_TILES": "3", "LIGHTDOCK_TILED_WAVES": "5", "LIGHTDOCK_TILED_SEGMENTS": "2"},
+    {"LIGHTDOCK_TILED_CHUNK_TILES": "64", "LIGHTDOCK_TILED_WAVES": "16", "LIGHTDOCK_TILED_SEGMENTS": "1"},
+])
+@pytest.mark.parametrize("name", ["1ppe", "1k4c", "2uuy"])
+def test_dfire_kernel_variants_agree(pkg, orc, table, scorers, name, env):
+    """The all-pairs kernel and the box-culled tiled kernel (in several work splits, incl.
+    several receptor chunks per pose) are two routes to the same sum: both match the oracle,
+    and the in-cutoff pair counts -- which no culling may change -- are identical."""
+    torch = pytest.importorskip("torch")
+    default_hip, cpu = scorers(name)
+    method, rec, lig, kw = case_kwargs(name, orc, table)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        variant = pkg.Scorer.from_pdb(method, rec, lig, **kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    poses = case_positions(name, orc)[:64]
+    want = cpu.energy_rows(poses)
+    assert rel_err(variant.energy_batch(poses), want) < REL_TOL
+    dev = torch.device("cuda:0")
+    d_poses = torch.from_numpy(poses).to(dev)
+    counts = []
+    for s in (variant, default_hip):
+        d_out = torch.zeros(64, dtype=torch.float64, device=dev)
+        d_cnt = torch.zeros(64, dtype=torch.int32, device=dev)
+        s.energy_batch_device(64, d_poses.data_ptr(), poses.shape[1], d_out.data_ptr(), None, d_cnt.data_ptr())
+        torch.cuda.synchronize()
+        counts.append(d_cnt.cpu().numpy())
+    assert np.array_equal(counts[0], counts[1])
+    stats = np.array([cpu.energy_ex_row(p)[1][5] for p in poses[:16]])
+    assert np.array_equal(counts[0][:16].astype(np.int64), stats.astype(np.int64))
