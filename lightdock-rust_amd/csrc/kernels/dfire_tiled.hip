@@ -2,27 +2,29 @@
 //
 // DFIRE only counts pairs closer than 15 A (src/dfire.rs:334): about 1 % of the 11.2 M atom
 // pairs of the 1k4c example.  This kernel evaluates the same sum as src/dfire.rs:325-345 but
-// throws away whole blocks of pairs by box distance before touching them:
+// discards whole blocks of pairs by box distance before touching them.
 //
-//   workgroup = (pose, receptor chunk); up to 16 wave64s.
-//   1. receptor chunk: coalesced SoA loads from HBM, ANM deformation (src/dfire.rs:304-320),
-//      32-byte f64 records into LDS; then one f32 bounding box (rounded outwards) per 8-atom
-//      subtile and per 64-atom tile, also in LDS.
-//   2. work item = (ligand tile of 64 atoms, range of receptor tiles), dealt round-robin to
-//      the waves.  The wave poses its ligand tile in registers (q v q^-1 + t, then ANM;
-//      src/dfire.rs:282-302), parks the posed records in its private LDS slice and builds the
-//      8 subtile boxes + the tile box with wave shuffles.
-//   3. 64 lanes test the tile box against 64 receptor tile boxes at once (ballot); for every
-//      surviving receptor tile, 64 lanes test the 8x8 subtile pairs at once (ballot).
-//   4. every surviving subtile pair is one wave iteration: lane (i, j) takes ligand atom i and
-//      receptor atom j of the pair -- 64 distinct atom pairs, all operands from LDS -- and runs
-//      the reference's pair body: f64 d2 in the reference's operation order, cutoff, distance
-//      bin (LUT, exact), potential[type_i][type_j][bin] gather, interface flags.
-//   5. wave64 shuffle reduction, cross-wave through LDS, one partial per (pose, chunk).
+// Shape: "ligand tile stationary, receptor tiles streamed".
+//   wave64 = (pose, ligand tile of 64 atoms); a workgroup is 1..16 such waves of one pose.
+//   1. The wave poses its 64 ligand atoms in registers (q v q^-1 + t, then ANM;
+//      src/dfire.rs:282-302), parks the 32-byte records in its private 2 KiB LDS slice and
+//      builds 8 subtile boxes (8 atoms each) + the tile box with xor-shuffle butterflies.
+//   2. 64 lanes test the tile box against 64 receptor tile boxes per ballot.
+//   3. Every surviving receptor tile is copied HBM/L2 -> LDS (64 lanes x 32 B, coalesced; the
+//      next tile's loads are issued before the current tile is processed), and 64 lanes test
+//      the 8 x 8 subtile-box pairs in one ballot.
+//   4. Every surviving subtile pair is one wave iteration of 64 distinct atom pairs: lane
+//      (i, j) takes ligand atom i and receptor atom j of the pair, both from LDS, and runs the
+//      reference's pair body: f64 d2 in the reference's operation order, cutoff, distance bin
+//      (exact LUT), potential[type_i][type_j][bin] gather, interface flags.  Two subtile pairs
+//      of one ligand row are in flight at a time so their LDS/L2 latencies overlap.
+//   5. wave64 shuffle reduction; one partial per (pose, workgroup).
+// The receptor image (records + boxes) is static in HBM/L2 and shared by all poses; with
+// receptor ANM (src/dfire.rs:304-320) dfire_prepare_receptor writes one image per pose first.
 //
-// Box tests are conservative (boxes rounded outwards, cutoff padded), so no in-cutoff pair is
-// ever dropped; the pair body itself is bit-identical to the all-pairs kernel.  Only the
-// order of the f64 += differs.  Compiled with -ffp-contract=off.  No MFMA (lookup/reduction).
+// Box tests are conservative (boxes rounded outwards, cutoff padded): no in-cutoff pair is
+// ever dropped, and the pair body is bit-identical to the all-pairs kernel; only the order of
+// the f64 += differs.  Compiled with -ffp-contract=off.  No MFMA (lookup/reduction).
 #include "dfire_tiled.hpp"
 
 #include <cmath>
@@ -47,19 +49,6 @@ __device__ __forceinline__ Quat qinverse(const Quat &q) {  // src/qt.rs:48-50
     return Quat{q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2};
 }
 
-struct alignas(16) AtomRec {
-    double x, y, z;
-    uint32_t tindex;
-    int32_t slot;
-};
-static_assert(sizeof(AtomRec) == 32, "AtomRec must be 32 bytes");
-
-struct alignas(16) Box {
-    float lox, loy, loz, pad0;
-    float hix, hiy, hiz, pad1;
-};
-static_assert(sizeof(Box) == 32, "Box must be 32 bytes");
-
 constexpr float kCut2Padded = 225.01f;  // 15 A cutoff + slack for the f32 box arithmetic
 
 __device__ __forceinline__ float round_down(double v) {
@@ -73,11 +62,34 @@ __device__ __forceinline__ float round_up(double v) {
 __device__ __forceinline__ float axis_gap(float lo_a, float hi_a, float lo_b, float hi_b) {
     return fmaxf(0.0f, fmaxf(lo_a - hi_b, lo_b - hi_a));
 }
-__device__ __forceinline__ float box_gap2(float lox, float loy, float loz, float hix, float hiy, float hiz, const Box &b) {
-    const float gx = axis_gap(lox, hix, b.lox, b.hix);
-    const float gy = axis_gap(loy, hiy, b.loy, b.hiy);
-    const float gz = axis_gap(loz, hiz, b.loz, b.hiz);
+struct BoxRegs {
+    float lox, loy, loz, hix, hiy, hiz;
+};
+__device__ __forceinline__ float box_gap2(const BoxRegs &a, const TiledBox &b) {
+    const float gx = axis_gap(a.lox, a.hix, b.lox, b.hix);
+    const float gy = axis_gap(a.loy, a.hiy, b.loy, b.hiy);
+    const float gz = axis_gap(a.loz, a.hiz, b.loz, b.hiz);
     return gx * gx + gy * gy + gz * gz;
+}
+// min/max over lane groups: masks 1,2,4 -> groups of 8 lanes; 8,16,32 -> the whole wave
+template <int FROM, int TO>
+__device__ __forceinline__ void box_butterfly(BoxRegs &b) {
+#pragma unroll
+    for (int m = FROM; m < TO; m <<= 1) {
+        b.lox = fminf(b.lox, __shfl_xor(b.lox, m, 64)); b.hix = fmaxf(b.hix, __shfl_xor(b.hix, m, 64));
+        b.loy = fminf(b.loy, __shfl_xor(b.loy, m, 64)); b.hiy = fmaxf(b.hiy, __shfl_xor(b.hiy, m, 64));
+        b.loz = fminf(b.loz, __shfl_xor(b.loz, m, 64)); b.hiz = fmaxf(b.hiz, __shfl_xor(b.hiz, m, 64));
+    }
+}
+__device__ __forceinline__ BoxRegs point_box(bool valid, double x, double y, double z) {
+    BoxRegs b;
+    b.lox = valid ? round_down(x) : INFINITY; b.hix = valid ? round_up(x) : -INFINITY;
+    b.loy = valid ? round_down(y) : INFINITY; b.hiy = valid ? round_up(y) : -INFINITY;
+    b.loz = valid ? round_down(z) : INFINITY; b.hiz = valid ? round_up(z) : -INFINITY;
+    return b;
+}
+__device__ __forceinline__ TiledBox to_box(const BoxRegs &b) {
+    return TiledBox{b.lox, b.loy, b.loz, 0.f, b.hix, b.hiy, b.hiz, 0.f};
 }
 
 __device__ __forceinline__ size_t round16(size_t v) { return (v + 15) & ~size_t(15); }
@@ -93,203 +105,209 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Receptor image: one wave per (pose, receptor tile); lane = atom.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void dfire_prepare_receptor(const PrepareReceptorLaunch P) {
+    const size_t pose = blockIdx.x / (unsigned)P.n_tiles;
+    const int tile = blockIdx.x % (unsigned)P.n_tiles;
+    if (P.active != nullptr && P.active[pose] == 0) return;
+    const int lane = threadIdx.x;
+    const int a = tile * 64 + lane;
+    const size_t pad = (size_t)P.n_tiles * 64;
+    double x = P.x[a], y = P.y[a], z = P.z[a];
+    if (P.num_anm > 0) {  // src/dfire.rs:304-320
+        const double *rec_nm = P.poses + pose * P.stride + 7;
+        for (int k = 0; k < P.num_anm; k++) {
+            const double c = rec_nm[k];
+            const double *m = P.modes + (size_t)k * 3 * pad;
+            x += m[a] * c;
+            y += m[pad + a] * c;
+            z += m[2 * pad + a] * c;
+        }
+    }
+    TiledAtom r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    r.tindex = P.tindex[a];
+    r.slot = P.slot[a];
+    P.atoms_out[pose * pad + a] = r;
+    BoxRegs b = point_box(a < P.n_real, x, y, z);
+    box_butterfly<1, 8>(b);
+    if ((lane & 7) == 0) P.sub_out[(pose * (size_t)P.n_tiles + tile) * 8 + (lane >> 3)] = to_box(b);
+    box_butterfly<8, 64>(b);
+    if (lane == 0) P.tile_out[pose * (size_t)P.n_tiles + tile] = to_box(b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pair kernel
+// ---------------------------------------------------------------------------------------------
+struct PairCtx {
+    const uint8_t *lut;
+    const double *bin_step;
+    const double *tab;  // table + ligand column base of this lane's ligand atom
+    double iface_d2;
+    uint32_t *pose_flags;
+    int rec_flag_words;
+};
+
+// distance bin of an in-cutoff d2 (src/dfire.rs:336-337) through the exact cell LUT
+__device__ __forceinline__ uint32_t dfire_bin(const PairCtx &c, double d2) {
+    const uint32_t code = c.lut[(int)(fmin(d2, 225.0) * 4.0)];
+    uint32_t bin = code & 0x7fu;
+    if (code & 0x80u) bin += d2 >= c.bin_step[bin + 1] ? 1u : 0u;  // a bin step falls inside this cell
+    return bin;
+}
+__device__ __forceinline__ void mark_interface(const PairCtx &c, const TiledAtom &L, const TiledAtom &R) {
+    // d <= 3.9 (src/dfire.rs:339-342); only restraint atoms / membrane beads carry a slot
+    if (R.slot >= 0) atomicOr(&c.pose_flags[R.slot >> 5], 1u << (R.slot & 31));
+    if (L.slot >= 0) atomicOr(&c.pose_flags[c.rec_flag_words + (L.slot >> 5)], 1u << (L.slot & 31));
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(1024) void dfire_tiled_pairs(const TiledLaunch T) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // ---- LDS carve (every offset a multiple of 16) ---------------------------------------
-    AtomRec *rec = reinterpret_cast<AtomRec *>(smem);
-    size_t off = (size_t)T.chunk_tiles * 64 * sizeof(AtomRec);
-    Box *sbox = reinterpret_cast<Box *>(smem + off);
-    off += (size_t)T.chunk_tiles * 8 * sizeof(Box);
-    Box *tbox = reinterpret_cast<Box *>(smem + off);
-    off += (size_t)T.chunk_tiles * sizeof(Box);
-    AtomRec *ligt_all = reinterpret_cast<AtomRec *>(smem + off);
-    off += (size_t)T.waves * 64 * sizeof(AtomRec);
-    uint8_t *lut = smem + off;
-    off += round16(kDfireLutCells);
+    uint8_t *lut = smem;
+    size_t off = round16(kDfireLutCells);
     double *bin_step = reinterpret_cast<double *>(smem + off);
     off += kDfireSteps * sizeof(double);
     double *red = reinterpret_cast<double *>(smem + off);
     off += kTiledMaxWaves * sizeof(double);
     uint32_t *red_cnt = reinterpret_cast<uint32_t *>(smem + off);  // [kTiledMaxWaves][2]
+    off += kTiledMaxWaves * 2 * sizeof(uint32_t);
+    TiledAtom *slices = reinterpret_cast<TiledAtom *>(smem + off);  // per wave: 64 ligand + 64 receptor records
 
     const int tid = threadIdx.x;
-    const int nthreads = blockDim.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t pose = blockIdx.x / (unsigned)T.n_chunks;
-    const int chunk = blockIdx.x % (unsigned)T.n_chunks;
+    const size_t pose = blockIdx.x / (unsigned)T.n_groups;
+    const int group = blockIdx.x % (unsigned)T.n_groups;
     if (T.active != nullptr && T.active[pose] == 0) return;
 
-    const double *row = T.poses + pose * T.stride;
-    const double tx = row[0], ty = row[1], tz = row[2];
-    const Quat q{row[3], row[4], row[5], row[6]};
-    const Quat qinv = qinverse(q);
-    const bool anm_rec = T.use_anm && T.rec.num_anm > 0;
-    const bool anm_lig = T.use_anm && T.lig.num_anm > 0;
-    const double *rec_nm = row + 7;
-    const double *lig_nm = row + 7 + (T.use_anm ? T.rec.num_anm : 0);
-
-    // ---- 1. stage the receptor chunk ---------------------------------------------------------
-    const int tile0 = chunk * T.chunk_tiles;
-    const int rn_tiles = min(T.chunk_tiles, T.rec.n_tiles - tile0);
-    const int rn = rn_tiles * 64;
-    const int atom0 = tile0 * 64;
-    const size_t rec_pad = (size_t)T.rec.n_tiles * 64;
-    for (int i = tid; i < rn; i += nthreads) {
-        const int a = atom0 + i;
-        double x = T.rec.x[a], y = T.rec.y[a], z = T.rec.z[a];
-        if (anm_rec) {
-            for (int k = 0; k < T.rec.num_anm; k++) {
-                const double c = rec_nm[k];
-                const double *m = T.rec.modes + (size_t)k * 3 * rec_pad;
-                x += m[a] * c;
-                y += m[rec_pad + a] * c;
-                z += m[2 * rec_pad + a] * c;
-            }
-        }
-        AtomRec r;
-        r.x = x;
-        r.y = y;
-        r.z = z;
-        r.tindex = T.rec.tindex[a];
-        r.slot = T.rec.slot[a];
-        rec[i] = r;
-    }
-    for (int i = tid; i < kDfireLutCells / 4; i += nthreads)
+    for (int i = tid; i < kDfireLutCells / 4; i += blockDim.x)
         reinterpret_cast<uint32_t *>(lut)[i] = reinterpret_cast<const uint32_t *>(T.lut)[i];
     if (tid < kDfireSteps) bin_step[tid] = T.bin_step[tid];
     __syncthreads();
 
-    for (int s = tid; s < rn_tiles * 8; s += nthreads) {  // subtile boxes over the real atoms
-        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int k = 0; k < 8; k++) {
-            const int i = s * 8 + k;
-            if (atom0 + i < T.rec.n_real) {
-                const AtomRec r = rec[i];
-                lo[0] = fmin(lo[0], r.x); hi[0] = fmax(hi[0], r.x);
-                lo[1] = fmin(lo[1], r.y); hi[1] = fmax(hi[1], r.y);
-                lo[2] = fmin(lo[2], r.z); hi[2] = fmax(hi[2], r.z);
-            }
-        }
-        Box b;
-        b.lox = round_down(lo[0]); b.loy = round_down(lo[1]); b.loz = round_down(lo[2]); b.pad0 = 0.f;
-        b.hix = round_up(hi[0]); b.hiy = round_up(hi[1]); b.hiz = round_up(hi[2]); b.pad1 = 0.f;
-        sbox[s] = b;
-    }
-    __syncthreads();
-    for (int t = tid; t < rn_tiles; t += nthreads) {  // tile boxes
-        Box b = sbox[t * 8];
-        for (int k = 1; k < 8; k++) {
-            const Box c = sbox[t * 8 + k];
-            b.lox = fminf(b.lox, c.lox); b.loy = fminf(b.loy, c.loy); b.loz = fminf(b.loz, c.loz);
-            b.hix = fmaxf(b.hix, c.hix); b.hiy = fmaxf(b.hiy, c.hiy); b.hiz = fmaxf(b.hiz, c.hiz);
-        }
-        tbox[t] = b;
-    }
-    __syncthreads();
-
-    // ---- 2..4 work items ------------------------------------------------------------------------
-    AtomRec *ligt = ligt_all + wave * 64;
-    uint32_t *pose_flags = T.flags + pose * (size_t)(T.rec.flag_words + T.lig.flag_words);
-    const size_t lig_pad = (size_t)T.lig.n_tiles * 64;
-    const int n_lt = T.lig.n_tiles;
-    const int items = n_lt * T.segments;
+    TiledAtom *ligt = slices + wave * 128;
+    TiledAtom *rect = ligt + 64;
     const int li = lane >> 3, lj = lane & 7;
     double acc = 0.0;
     uint32_t cnt = 0, tested = 0;
 
-    for (int item = wave; item < items; item += T.waves) {
-        const int LT = item % n_lt;
-        const int seg = item / n_lt;
-        const int seg_lo = seg * rn_tiles / T.segments;
-        const int seg_hi = (seg + 1) * rn_tiles / T.segments;
+    const int LT = group * T.waves + wave;
+    if (LT < T.lig.n_tiles) {
+        const double *row = T.poses + pose * T.stride;
+        const TiledAtom *rec_atoms = T.rec.atoms + pose * T.rec.pose_stride_atoms;
+        const TiledBox *rec_sub = T.rec.sub_boxes + pose * T.rec.pose_stride_sub;
+        const TiledBox *rec_tile = T.rec.tile_boxes + pose * T.rec.pose_stride_tile;
 
-        // pose this lane's ligand atom (src/dfire.rs:282-302)
+        // ---- 1. pose this lane's ligand atom ---------------------------------------------------
         const int la = LT * 64 + lane;
         const bool valid = la < T.lig.n_real;
-        AtomRec me;
+        TiledAtom me;
         {
+            const double tx = row[0], ty = row[1], tz = row[2];
+            const Quat q{row[3], row[4], row[5], row[6]};
+            const Quat qinv = qinverse(q);
             const Quat v{0.0, T.lig.x[la], T.lig.y[la], T.lig.z[la]};
             const Quat r = qmul(qmul(q, v), qinv);
             double px = r.x + tx, py = r.y + ty, pz = r.z + tz;
-            if (anm_lig) {
+            if (T.use_anm && T.lig.num_anm > 0) {
+                const double *lig_nm = row + 7 + T.anm_rec;
+                const size_t pad = (size_t)T.lig.n_tiles * 64;
                 for (int k = 0; k < T.lig.num_anm; k++) {
                     const double c = lig_nm[k];
-                    const double *m = T.lig.modes + (size_t)k * 3 * lig_pad;
+                    const double *m = T.lig.modes + (size_t)k * 3 * pad;
                     px += m[la] * c;
-                    py += m[lig_pad + la] * c;
-                    pz += m[2 * lig_pad + la] * c;
+                    py += m[pad + la] * c;
+                    pz += m[2 * pad + la] * c;
                 }
             }
-            me.x = valid ? px : 1.0e30;  // padding: far away, opposite side of the receptor's padding
+            me.x = valid ? px : 1.0e30;  // padding: far away, on the other side of the receptor's padding
             me.y = valid ? py : 0.0;
             me.z = valid ? pz : 0.0;
             me.tindex = T.lig.tindex[la];
             me.slot = T.lig.slot[la];
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // earlier reads of ligt are done
         ligt[lane] = me;
+        BoxRegs sub = point_box(valid, me.x, me.y, me.z);
+        box_butterfly<1, 8>(sub);  // lanes 8a..8a+7 now hold the box of ligand subtile a
+        BoxRegs whole = sub;
+        box_butterfly<8, 64>(whole);
 
-        // subtile boxes (8 lanes each) and the tile box by xor butterflies
-        float slox = valid ? round_down(me.x) : INFINITY, shix = valid ? round_up(me.x) : -INFINITY;
-        float sloy = valid ? round_down(me.y) : INFINITY, shiy = valid ? round_up(me.y) : -INFINITY;
-        float sloz = valid ? round_down(me.z) : INFINITY, shiz = valid ? round_up(me.z) : -INFINITY;
-#pragma unroll
-        for (int m = 1; m < 8; m <<= 1) {
-            slox = fminf(slox, __shfl_xor(slox, m, 64)); shix = fmaxf(shix, __shfl_xor(shix, m, 64));
-            sloy = fminf(sloy, __shfl_xor(sloy, m, 64)); shiy = fmaxf(shiy, __shfl_xor(shiy, m, 64));
-            sloz = fminf(sloz, __shfl_xor(sloz, m, 64)); shiz = fmaxf(shiz, __shfl_xor(shiz, m, 64));
-        }
-        float tlox = slox, thix = shix, tloy = sloy, thiy = shiy, tloz = sloz, thiz = shiz;
-#pragma unroll
-        for (int m = 8; m < 64; m <<= 1) {
-            tlox = fminf(tlox, __shfl_xor(tlox, m, 64)); thix = fmaxf(thix, __shfl_xor(thix, m, 64));
-            tloy = fminf(tloy, __shfl_xor(tloy, m, 64)); thiy = fmaxf(thiy, __shfl_xor(thiy, m, 64));
-            tloz = fminf(tloz, __shfl_xor(tloz, m, 64)); thiz = fmaxf(thiz, __shfl_xor(thiz, m, 64));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // ligt is written before anyone reads it
+        PairCtx ctx;
+        ctx.lut = lut;
+        ctx.bin_step = bin_step;
+        ctx.tab = T.table;
+        ctx.iface_d2 = T.iface_d2;
+        ctx.pose_flags = T.flags + pose * (size_t)(T.rec.flag_words + T.lig.flag_words);
+        ctx.rec_flag_words = T.rec.flag_words;
 
-        // 64 receptor tiles per ballot
-        bool tile_near = false;
-        if (lane >= seg_lo && lane < seg_hi) tile_near = box_gap2(tlox, tloy, tloz, thix, thiy, thiz, tbox[lane]) <= kCut2Padded;
-        unsigned long long rtmask = __ballot(tile_near);
-        while (rtmask) {
-            const int RT = __ffsll(rtmask) - 1;
+        // ---- 2. receptor tiles, 64 per ballot ---------------------------------------------------
+        for (int base = 0; base < T.rec.n_tiles; base += 64) {
+            bool tile_near = false;
+            if (base + lane < T.rec.n_tiles) tile_near = box_gap2(whole, rec_tile[base + lane]) <= kCut2Padded;
+            unsigned long long rtmask = __ballot(tile_near);
+            if (rtmask == 0) continue;
+
+            // ---- 3. stream the surviving tiles; the next tile's loads fly while this one is processed
+            int RT = base + __ffsll(rtmask) - 1;
             rtmask &= rtmask - 1;
-            // lane (li, lj): ligand subtile li (its box is in this lane's registers) x receptor subtile lj
-            const bool sub_near = box_gap2(slox, sloy, sloz, shix, shiy, shiz, sbox[RT * 8 + lj]) <= kCut2Padded;
-            unsigned long long smask = __ballot(sub_near);
-            if (COUNT) tested += (uint32_t)__popcll(smask);
-            const AtomRec *rtile = rec + RT * 64;
-            while (smask) {
-                const int a = (__ffsll(smask) - 1) >> 3;
-                uint32_t am = (uint32_t)(smask >> (8 * a)) & 0xffu;
-                smask &= ~(0xffull << (8 * a));
-                const AtomRec L = ligt[a * 8 + li];
-                const double *tab = T.table + L.tindex;
-                while (am) {
-                    const int b = __ffs(am) - 1;
-                    am &= am - 1;
-                    const AtomRec R = rtile[b * 8 + lj];
-                    // (x1 - la[0])^2 + (y1 - la[1])^2 + (z1 - la[2])^2, src/dfire.rs:331-333
-                    const double dx = R.x - L.x, dy = R.y - L.y, dz = R.z - L.z;
-                    const double d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 <= 225.0) {
-                        // DIST_TO_BINS[(sqrt(d2)*2-1) as usize] - 1, src/dfire.rs:336-337, via the
-                        // exact cell LUT (DESIGN.md "bin LUT"); 0x80 marks the few cells whose last
-                        // double the correctly rounded sqrt pushes into the next bin.
-                        const uint32_t code = lut[(int)(d2 * 4.0)];
-                        uint32_t bin = code & 0x7fu;
-                        if (code & 0x80u) bin += d2 >= bin_step[bin + 1] ? 1u : 0u;
-                        acc += tab[R.tindex + bin];  // src/dfire.rs:338
-                        if (COUNT) cnt++;
-                        if (d2 <= T.iface_d2) {  // d <= 3.9, src/dfire.rs:339-342
-                            if (R.slot >= 0) atomicOr(&pose_flags[R.slot >> 5], 1u << (R.slot & 31));
-                            if (L.slot >= 0) atomicOr(&pose_flags[T.rec.flag_words + (L.slot >> 5)], 1u << (L.slot & 31));
-                        }
+            TiledAtom next_atom = rec_atoms[(size_t)RT * 64 + lane];
+            TiledBox next_box = rec_sub[(size_t)RT * 8 + lj];
+            for (;;) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // reads of the previous tile are done
+                rect[lane] = next_atom;
+                const bool sub_near = box_gap2(sub, next_box) <= kCut2Padded;  // ligand subtile li x receptor subtile lj
+                unsigned long long smask = __ballot(sub_near);
+                const bool more = rtmask != 0;
+                if (more) {
+                    RT = base + __ffsll(rtmask) - 1;
+                    rtmask &= rtmask - 1;
+                    next_atom = rec_atoms[(size_t)RT * 64 + lane];
+                    next_box = rec_sub[(size_t)RT * 8 + lj];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // rect/ligt written before anyone reads
+                if (COUNT) tested += (uint32_t)__popcll(smask);
+
+                // ---- 4. surviving subtile pairs, one ligand row (a) at a time ------------------
+                while (smask) {
+                    const int a = (__ffsll(smask) - 1) >> 3;
+                    uint32_t am = (uint32_t)(smask >> (8 * a)) & 0xffu;
+                    smask &= ~(0xffull << (8 * a));
+                    const TiledAtom L = ligt[a * 8 + li];
+                    const double *tab = ctx.tab + L.tindex;
+                    while (am) {
+                        const int b0 = __ffs(am) - 1;
+                        am &= am - 1;
+                        const bool two = am != 0;
+                        const int b1 = two ? __ffs(am) - 1 : b0;
+                        am &= am - 1;  // am == 0 stays 0
+                        const TiledAtom R0 = rect[b0 * 8 + lj];
+                        const TiledAtom R1 = rect[b1 * 8 + lj];
+                        // (x1 - la[0])^2 + (y1 - la[1])^2 + (z1 - la[2])^2, src/dfire.rs:331-333
+                        const double dx0 = R0.x - L.x, dy0 = R0.y - L.y, dz0 = R0.z - L.z;
+                        const double dx1 = R1.x - L.x, dy1 = R1.y - L.y, dz1 = R1.z - L.z;
+                        const double d20 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
+                        const double d21 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
+                        const bool hit0 = d20 <= 225.0;
+                        const bool hit1 = two && d21 <= 225.0;
+                        const uint32_t bin0 = dfire_bin(ctx, d20);
+                        const uint32_t bin1 = dfire_bin(ctx, d21);
+                        double v0 = 0.0, v1 = 0.0;
+                        if (hit0) v0 = tab[R0.tindex + bin0];  // src/dfire.rs:338
+                        if (hit1) v1 = tab[R1.tindex + bin1];
+                        acc += v0;
+                        acc += v1;
+                        if (COUNT) cnt += (hit0 ? 1u : 0u) + (hit1 ? 1u : 0u);
+                        if (hit0 && d20 <= ctx.iface_d2) mark_interface(ctx, L, R0);
+                        if (hit1 && d21 <= ctx.iface_d2) mark_interface(ctx, L, R1);
                     }
                 }
+                if (!more) break;
             }
         }
     }
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(1024) void dfire_tiled_pairs(const TiledLaunch T) {
                 t += red_cnt[2 * w + 1];
             }
         }
-        const size_t slot = pose * (size_t)T.n_chunks + chunk;
+        const size_t slot = pose * (size_t)T.n_groups + group;
         T.partial[2 * slot] = s;
         T.partial[2 * slot + 1] = 0.0;
         if (COUNT) {
@@ -325,41 +343,31 @@ __global__ __launch_bounds__(1024) void dfire_tiled_pairs(const TiledLaunch T) {
     }
 }
 
-size_t lds_bytes(int chunk_tiles, int waves) {
-    size_t b = (size_t)chunk_tiles * 64 * sizeof(AtomRec) + (size_t)chunk_tiles * 8 * sizeof(Box) +
-               (size_t)chunk_tiles * sizeof(Box) + (size_t)waves * 64 * sizeof(AtomRec);
-    b += ((kDfireLutCells + 15) & ~15) + kDfireSteps * sizeof(double);
-    b += kTiledMaxWaves * sizeof(double) + kTiledMaxWaves * 2 * sizeof(uint32_t) + 16;
-    return b;
-}
-
 }  // namespace
 
-size_t tiled_kernel_lds_bytes(const TiledLaunch &t) { return lds_bytes(t.chunk_tiles, t.waves); }
-
-int tiled_max_chunk_tiles(int waves) {
-    const size_t budget = 160 * 1024;
-    int tiles = 1;
-    while (tiles < 64 && lds_bytes(tiles + 1, waves) <= budget) tiles++;  // 64: one ballot covers the chunk
-    return tiles;
-}
-
-hipError_t configure_dfire_tiled() {  // > 64 KiB of dynamic LDS has to be requested explicitly, per device
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dfire_tiled_pairs<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(dfire_tiled_pairs<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+size_t tiled_kernel_lds_bytes(const TiledLaunch &t) {
+    size_t b = ((kDfireLutCells + 15) & ~15) + kDfireSteps * sizeof(double);
+    b += kTiledMaxWaves * sizeof(double) + kTiledMaxWaves * 2 * sizeof(uint32_t);
+    b += (size_t)t.waves * 128 * sizeof(TiledAtom);
+    return b;
 }
 
 hipError_t launch_dfire_tiled(const TiledLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    const size_t blocks = t.n_poses * (size_t)t.n_chunks;
+    const size_t blocks = t.n_poses * (size_t)t.n_groups;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     const size_t lds = tiled_kernel_lds_bytes(t);
     const dim3 grid((unsigned)blocks), block((unsigned)t.waves * 64);
     if (t.count_partial != nullptr) hipLaunchKernelGGL((dfire_tiled_pairs<true>), grid, block, lds, stream, t);
     else hipLaunchKernelGGL((dfire_tiled_pairs<false>), grid, block, lds, stream, t);
+    return hipGetLastError();
+}
+
+hipError_t launch_prepare_receptor(const PrepareReceptorLaunch &p, hipStream_t stream) {
+    if (p.n_poses == 0 || p.n_tiles == 0) return hipSuccess;
+    const size_t blocks = p.n_poses * (size_t)p.n_tiles;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(dfire_prepare_receptor, dim3((unsigned)blocks), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

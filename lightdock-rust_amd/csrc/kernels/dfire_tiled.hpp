@@ -16,43 +16,85 @@ namespace ld {
 
 constexpr int kTiledMaxWaves = 16;
 
-// A molecule in tile order, padded to whole 64-atom tiles; padding atoms sit at x = 1e30.
-struct TiledMolecule {
-    int n_real = 0;   // atoms that are not padding (padding only at the tail)
-    int n_tiles = 0;  // 64-atom tiles; arrays hold n_tiles * 64 entries
+// 32-byte atom record, the unit both molecules are handled in inside the kernel.
+struct alignas(16) TiledAtom {
+    double x, y, z;
+    uint32_t tindex;  // receptor: type*3380, ligand: type*20 (src/dfire.rs:338)
+    int32_t slot;     // interface-flag bit or -1
+};
+static_assert(sizeof(TiledAtom) == 32, "TiledAtom must be 32 bytes");
+
+// f32 bounding box rounded outwards; an empty box has lo = +inf, hi = -inf.
+struct alignas(16) TiledBox {
+    float lox, loy, loz, pad0;
+    float hix, hiy, hiz, pad1;
+};
+static_assert(sizeof(TiledBox) == 32, "TiledBox must be 32 bytes");
+
+// The receptor as the kernel streams it: records in tile order (padding atoms at x = -1e30),
+// one box per 8-atom subtile and per 64-atom tile.  Without receptor ANM this is static data
+// (pose_stride_* = 0); with it, dfire_prepare_receptor writes one image per pose.
+struct TiledReceptor {
+    int n_real = 0;
+    int n_tiles = 0;
+    const TiledAtom *atoms = nullptr;   // [n_tiles*64]
+    const TiledBox *sub_boxes = nullptr;   // [n_tiles*8]
+    const TiledBox *tile_boxes = nullptr;  // [n_tiles]
+    size_t pose_stride_atoms = 0, pose_stride_sub = 0, pose_stride_tile = 0;  // elements per pose image
+    int flag_words = 0;
+};
+
+// The ligand in tile order, SoA, padded to whole tiles (the kernel re-places padding after posing).
+struct TiledLigand {
+    int n_real = 0;
+    int n_tiles = 0;
     const double *x = nullptr, *y = nullptr, *z = nullptr;
-    const uint32_t *tindex = nullptr;  // receptor: type*3380, ligand: type*20
-    const int32_t *slot = nullptr;     // interface-flag bit or -1
+    const uint32_t *tindex = nullptr;
+    const int32_t *slot = nullptr;
     int num_anm = 0;
-    const double *modes = nullptr;     // [mode][xyz][n_tiles*64]
+    const double *modes = nullptr;  // [mode][xyz][n_tiles*64]
     int flag_words = 0;
 };
 
 struct TiledLaunch {
-    TiledMolecule rec, lig;
+    TiledReceptor rec;
+    TiledLigand lig;
     int use_anm = 0;
-    int waves = 8;        // wave64s per workgroup
-    int chunk_tiles = 0;  // receptor tiles staged in LDS by one workgroup
-    int n_chunks = 0;
-    int segments = 1;     // the chunk's tiles are split into this many ranges; work item = (ligand tile, range)
+    int anm_rec = 0;      // pose-row columns taken by receptor ANM extents
+    int waves = 1;        // wave64s per workgroup; each wave owns one ligand tile of one pose
+    int n_groups = 0;     // workgroups per pose = ceil(lig.n_tiles / waves)
     const double *table = nullptr;
-    const uint8_t *lut = nullptr;       // cell -> bin | 0x80 if the cell's last double may belong to the next bin
-    const double *bin_step = nullptr;   // kDfireSteps
+    const uint8_t *lut = nullptr;      // cell -> bin | 0x80 if a bin step falls inside the cell
+    const double *bin_step = nullptr;  // kDfireSteps
     double iface_d2 = 0.0;
     const double *poses = nullptr;
     size_t stride = 0;
     const uint8_t *active = nullptr;
     size_t n_poses = 0;
-    double *partial = nullptr;          // [pose][chunk][2]
+    double *partial = nullptr;           // [pose][group][2]
     uint32_t *flags = nullptr;
-    uint32_t *count_partial = nullptr;  // [pose][chunk] or nullptr
-    uint32_t *tested_partial = nullptr; // [pose][chunk]: 8x8 blocks actually evaluated (diagnostics) or nullptr
+    uint32_t *count_partial = nullptr;   // [pose][group] or nullptr
+    uint32_t *tested_partial = nullptr;  // [pose][group]: 8x8 blocks evaluated (diagnostics) or nullptr
+};
+
+// Receptor image per pose for runs with receptor ANM (src/dfire.rs:304-320).
+struct PrepareReceptorLaunch {
+    int n_real = 0, n_tiles = 0;
+    const double *x = nullptr, *y = nullptr, *z = nullptr;  // tile order, padded
+    const uint32_t *tindex = nullptr;
+    const int32_t *slot = nullptr;
+    int num_anm = 0;
+    const double *modes = nullptr;  // [mode][xyz][n_tiles*64]
+    const double *poses = nullptr;
+    size_t stride = 0;
+    const uint8_t *active = nullptr;
+    size_t n_poses = 0;
+    TiledAtom *atoms_out = nullptr;
+    TiledBox *sub_out = nullptr, *tile_out = nullptr;
 };
 
 size_t tiled_kernel_lds_bytes(const TiledLaunch &t);
-// Largest chunk (in tiles) whose LDS image fits beside `waves` ligand tiles.
-int tiled_max_chunk_tiles(int waves);
-hipError_t configure_dfire_tiled();  // once per device, before the first launch
 hipError_t launch_dfire_tiled(const TiledLaunch &t, hipStream_t stream);
+hipError_t launch_prepare_receptor(const PrepareReceptorLaunch &p, hipStream_t stream);
 
 }  // namespace ld

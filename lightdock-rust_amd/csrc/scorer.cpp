@@ -290,13 +290,13 @@ Scorer::Scorer(const ld_scorer_desc &desc) {
     }
 }
 
-void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, const DeviceMolecule &plain, TiledMolecule &out) {
+// Tile-ordered SoA copy of one molecule (host/spatial_order.hpp); padding atoms at -1e30
+// (receptor) / +1e30 (ligand) so that no padding/padding pair can ever look close.
+void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, TiledSoA &out) {
     const size_t n = m.n_atoms;
     const std::vector<uint32_t> order = spatial_tile_order(m.coordinates, n);
     const size_t np = order.size();
     const uint32_t kPad = std::numeric_limits<uint32_t>::max();
-    // padding atoms: receptor at -1e30, ligand at +1e30 (the kernel re-places ligand padding
-    // after posing), so that no padding/padding pair can ever look close
     std::vector<double> x(np, is_receptor ? -1.0e30 : 1.0e30), y(np, 0.0), z(np, 0.0);
     std::vector<uint32_t> t(np, 0);
     std::vector<int32_t> slot(np, -1);
@@ -320,7 +320,6 @@ void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, const
     out.z = arena_.upload(z);
     out.tindex = arena_.upload(t);
     out.slot = arena_.upload(slot);
-    out.flag_words = plain.flag_words;
     out.num_anm = 0;
     out.modes = nullptr;
     if (use_anm_ && m.num_anm > 0) {
@@ -336,10 +335,24 @@ void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, const
 }
 
 void Scorer::build_tiled(const ld_scorer_desc &desc) {
-    hip_check(configure_dfire_tiled(), "hipFuncSetAttribute(dynamic LDS)");
-    upload_tiled_molecule(desc.receptor, true, pair_.rec, tiled_.rec);
-    upload_tiled_molecule(desc.ligand, false, pair_.lig, tiled_.lig);
+    upload_tiled_molecule(desc.receptor, true, tiled_rec_soa_);
+    TiledSoA lig;
+    upload_tiled_molecule(desc.ligand, false, lig);
+    tiled_.lig.n_real = lig.n_real;
+    tiled_.lig.n_tiles = lig.n_tiles;
+    tiled_.lig.x = lig.x;
+    tiled_.lig.y = lig.y;
+    tiled_.lig.z = lig.z;
+    tiled_.lig.tindex = lig.tindex;
+    tiled_.lig.slot = lig.slot;
+    tiled_.lig.num_anm = lig.num_anm;
+    tiled_.lig.modes = lig.modes;
+    tiled_.lig.flag_words = pair_.lig.flag_words;
+    tiled_.rec.n_real = tiled_rec_soa_.n_real;
+    tiled_.rec.n_tiles = tiled_rec_soa_.n_tiles;
+    tiled_.rec.flag_words = pair_.rec.flag_words;
     tiled_.use_anm = use_anm_ ? 1 : 0;
+    tiled_.anm_rec = (int)anm_rec();
     tiled_.table = pair_.table;
     tiled_.bin_step = pair_.bin_step;
     tiled_.iface_d2 = pair_.iface_d2;
@@ -352,44 +365,51 @@ void Scorer::build_tiled(const ld_scorer_desc &desc) {
         }
         tiled_.lut = arena_.upload(code);
     }
-    // Work split.  items = ligand tiles x receptor-tile ranges, dealt round-robin to W waves;
-    // every item re-poses its ligand tile, so ranges cost a little.  Minimise
-    // ceil(items / W) * (c_pose + c_pairs / S), c_pose : c_pairs ~ 0.08, prefer more waves.
-    const int n_lt = tiled_.lig.n_tiles, nt = tiled_.rec.n_tiles;
-    int best_w = 16, best_s = 1;
-    double best_cost = 1e300;
-    for (int w = 16; w >= 8; w--) {
-        const int fit = tiled_max_chunk_tiles(w);
-        const int chunks = (nt + fit - 1) / fit;
-        const int ct = (nt + chunks - 1) / chunks;
-        for (int s = 1; s <= 4 && s <= ct; s++) {
-            const int items = n_lt * s;
-            const double cost = chunks * ((items + w - 1) / w) * (0.08 + 1.0 / s);
-            if (cost < best_cost - 1e-12) {
-                best_cost = cost;
-                best_w = w;
-                best_s = s;
-            }
-        }
-    }
+    int waves = 4;  // measured on MI355X (1k4c, 1ppe): 4 waves per workgroup beat 1, 2 and 8
     if (const char *e = std::getenv("LIGHTDOCK_TILED_WAVES")) {
         int v = std::atoi(e);
-        if (v >= 1 && v <= kTiledMaxWaves) best_w = v;
+        if (v >= 1 && v <= kTiledMaxWaves) waves = v;
     }
-    if (const char *e = std::getenv("LIGHTDOCK_TILED_SEGMENTS")) {
-        int v = std::atoi(e);
-        if (v >= 1 && v <= 8) best_s = v;
+    tiled_.waves = waves;
+    tiled_.n_groups = (tiled_.lig.n_tiles + waves - 1) / waves;
+
+    rec_anm_per_pose_ = use_anm_ && tiled_rec_soa_.num_anm > 0;
+    if (!rec_anm_per_pose_) {
+        // static receptor image (records + subtile/tile boxes), built once by the same kernel
+        // that builds the per-pose images when the receptor has ANM
+        const size_t pad = (size_t)tiled_.rec.n_tiles * 64;
+        TiledAtom *atoms = static_cast<TiledAtom *>(arena_.alloc_bytes(pad * sizeof(TiledAtom)));
+        TiledBox *sub = static_cast<TiledBox *>(arena_.alloc_bytes(pad / 8 * sizeof(TiledBox)));
+        TiledBox *tile = static_cast<TiledBox *>(arena_.alloc_bytes(pad / 64 * sizeof(TiledBox)));
+        PrepareReceptorLaunch p = prepare_launch(nullptr, 0, nullptr, 1);
+        p.num_anm = 0;
+        p.atoms_out = atoms;
+        p.sub_out = sub;
+        p.tile_out = tile;
+        hip_check(launch_prepare_receptor(p, stream_), "launch dfire_prepare_receptor");
+        hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        tiled_.rec.atoms = atoms;
+        tiled_.rec.sub_boxes = sub;
+        tiled_.rec.tile_boxes = tile;
     }
-    tiled_.waves = best_w;
-    tiled_.segments = best_s;
-    int fit = tiled_max_chunk_tiles(best_w);
-    if (const char *e = std::getenv("LIGHTDOCK_TILED_CHUNK_TILES")) {
-        int v = std::atoi(e);
-        if (v >= 1 && v <= fit) fit = v;
-    }
-    tiled_.n_chunks = (nt + fit - 1) / fit;
-    tiled_.chunk_tiles = (nt + tiled_.n_chunks - 1) / tiled_.n_chunks;
-    if (tiled_.segments > tiled_.chunk_tiles) tiled_.segments = tiled_.chunk_tiles;
+}
+
+PrepareReceptorLaunch Scorer::prepare_launch(const double *poses, size_t stride, const uint8_t *active, size_t n) const {
+    PrepareReceptorLaunch p;
+    p.n_real = tiled_rec_soa_.n_real;
+    p.n_tiles = tiled_rec_soa_.n_tiles;
+    p.x = tiled_rec_soa_.x;
+    p.y = tiled_rec_soa_.y;
+    p.z = tiled_rec_soa_.z;
+    p.tindex = tiled_rec_soa_.tindex;
+    p.slot = tiled_rec_soa_.slot;
+    p.num_anm = tiled_rec_soa_.num_anm;
+    p.modes = tiled_rec_soa_.modes;
+    p.poses = poses;
+    p.stride = stride;
+    p.active = active;
+    p.n_poses = n;
+    return p;
 }
 
 Scorer::~Scorer() {
@@ -401,13 +421,16 @@ Scorer::~Scorer() {
     ws_flags_.release();
     ws_counts_.release();
     ws_tested_.release();
+    ws_rec_atoms_.release();
+    ws_rec_sub_.release();
+    ws_rec_tile_.release();
     ws_poses_.release();
     ws_energies_.release();
 }
 
 void Scorer::reserve_workspace(size_t n_poses, bool counts) {
     const size_t words = (size_t)(pair_.rec.flag_words + pair_.lig.flag_words);
-    const size_t chunks = (size_t)std::max(pair_.n_chunks, use_tiled_ ? tiled_.n_chunks : 0);
+    const size_t chunks = (size_t)std::max(pair_.n_chunks, use_tiled_ ? tiled_.n_groups : 0);
     ws_partial_.reserve(n_poses * chunks * 2 * sizeof(double));
     ws_flags_.reserve(std::max<size_t>(n_poses * words * sizeof(uint32_t), 16));
     if (counts) {
@@ -461,7 +484,24 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
         t.flags = p.flags;
         t.count_partial = p.count_partial;
         t.tested_partial = p.count_partial ? static_cast<uint32_t *>(ws_tested_.ptr) : nullptr;
-        p.n_chunks = t.n_chunks;  // the tail kernel folds this many partials
+        p.n_chunks = t.n_groups;  // the tail kernel folds this many partials
+        if (rec_anm_per_pose_) {  // one deformed receptor image per pose (src/dfire.rs:304-320)
+            const size_t pad = (size_t)t.rec.n_tiles * 64;
+            ws_rec_atoms_.reserve(n * pad * sizeof(TiledAtom));
+            ws_rec_sub_.reserve(n * (pad / 8) * sizeof(TiledBox));
+            ws_rec_tile_.reserve(n * (pad / 64) * sizeof(TiledBox));
+            PrepareReceptorLaunch pr = prepare_launch(d_poses, stride, d_active, n);
+            pr.atoms_out = static_cast<TiledAtom *>(ws_rec_atoms_.ptr);
+            pr.sub_out = static_cast<TiledBox *>(ws_rec_sub_.ptr);
+            pr.tile_out = static_cast<TiledBox *>(ws_rec_tile_.ptr);
+            hip_check(launch_prepare_receptor(pr, stream_), "launch dfire_prepare_receptor");
+            t.rec.atoms = pr.atoms_out;
+            t.rec.sub_boxes = pr.sub_out;
+            t.rec.tile_boxes = pr.tile_out;
+            t.rec.pose_stride_atoms = pad;
+            t.rec.pose_stride_sub = pad / 8;
+            t.rec.pose_stride_tile = pad / 64;
+        }
         hip_check(launch_dfire_tiled(t, stream_), "launch dfire_tiled_pairs");
     } else {
         hip_check(launch_pair_kernel(p, stream_), "launch pose_energy_pairs");
@@ -521,7 +561,7 @@ void Scorer::pair_kernel_time(double *total_ms, uint64_t *launches) {
 void Scorer::kernel_info(ld_kernel_info *out) const {
     out->pair_kernel_name = use_tiled_ ? "dfire_tiled_pairs" : pair_kernel_name(method_);
     out->block_threads = use_tiled_ ? (uint32_t)tiled_.waves * 64 : (uint32_t)kBlockThreads;
-    out->receptor_chunks = (uint32_t)(use_tiled_ ? tiled_.n_chunks : pair_.n_chunks);
+    out->receptor_chunks = (uint32_t)(use_tiled_ ? tiled_.n_groups : pair_.n_chunks);
     out->lds_bytes = (uint32_t)(use_tiled_ ? tiled_kernel_lds_bytes(tiled_) : pair_kernel_lds_bytes(pair_));
     out->pair_tests_per_pose = (uint64_t)pair_.rec.n * (uint64_t)pair_.lig.n;
     // DFIRE 26 B/atom (3 f64 + u16 type), DNA 48 B/atom (6 f64), + 240 B/atom

@@ -98,7 +98,16 @@ class Scorer {
                          std::vector<uint32_t> &membrane_slots);
     void reserve_workspace(size_t n_poses, bool counts);
     void build_tiled(const ld_scorer_desc &desc);
-    void upload_tiled_molecule(const ld_molecule &m, bool is_receptor, const DeviceMolecule &plain, TiledMolecule &out);
+    struct TiledSoA {  // a molecule in tile order, SoA, padded to whole tiles
+        int n_real = 0, n_tiles = 0;
+        const double *x = nullptr, *y = nullptr, *z = nullptr;
+        const uint32_t *tindex = nullptr;
+        const int32_t *slot = nullptr;
+        int num_anm = 0;
+        const double *modes = nullptr;
+    };
+    void upload_tiled_molecule(const ld_molecule &m, bool is_receptor, TiledSoA &out);
+    PrepareReceptorLaunch prepare_launch(const double *poses, size_t stride, const uint8_t *active, size_t n) const;
 
     int device_ = 0;
     hipStream_t stream_ = nullptr;
@@ -109,6 +118,9 @@ class Scorer {
     TailTables tail_;
     bool use_tiled_ = false;  // DFIRE: bounding-box culled kernel (default) instead of all-pairs
     TiledLaunch tiled_;
+    TiledSoA tiled_rec_soa_;          // receptor in tile order (input of dfire_prepare_receptor)
+    bool rec_anm_per_pose_ = false;   // receptor ANM: one receptor image per pose per launch
+    DeviceBuffer ws_rec_atoms_, ws_rec_sub_, ws_rec_tile_;
     std::vector<int32_t> host_slot_rec_, host_slot_lig_;  // per original atom, as uploaded to the all-pairs path
     HostMolecule host_rec_, host_lig_;
     DeviceBuffer ws_partial_, ws_flags_, ws_counts_, ws_tested_, ws_poses_, ws_energies_;

@@ -302,13 +302,13 @@ def test_real_dcparams_goldens_on_gpu(pkg, orc, real_dcparams):
 
 @pytest.mark.parametrize("env", [
     {"LIGHTDOCK_DFIRE_KERNEL": "allpairs"},
-    {"LIGHTDOCK_TILED_CHUNK_TILES": "3", "LIGHTDOCK_TILED_WAVES": "5", "LIGHTDOCK_TILED_SEGMENTS": "2"},
-    {"LIGHTDOCK_TILED_CHUNK_TILES": "64", "LIGHTDOCK_TILED_WAVES": "16", "LIGHTDOCK_TILED_SEGMENTS": "1"},
+    {"LIGHTDOCK_TILED_WAVES": "3"},
+    {"LIGHTDOCK_TILED_WAVES": "16"},
 ])
 @pytest.mark.parametrize("name", ["1ppe", "1k4c", "2uuy"])
 def test_dfire_kernel_variants_agree(pkg, orc, table, scorers, name, env):
-    """The all-pairs kernel and the box-culled tiled kernel (in several work splits, incl.
-    several receptor chunks per pose) are two routes to the same sum: both match the oracle,
+    """The all-pairs kernel and the box-culled tiled kernel (in several workgroup shapes) are
+    two routes to the same sum: both match the oracle,
     and the in-cutoff pair counts -- which no culling may change -- are identical."""
     torch = pytest.importorskip("torch")
     default_hip, cpu = scorers(name)
