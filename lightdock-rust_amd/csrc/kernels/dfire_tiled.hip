@@ -49,7 +49,12 @@ __device__ __forceinline__ Quat qinverse(const Quat &q) {  // src/qt.rs:48-50
     return Quat{q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2};
 }
 
-constexpr float kCut2Padded = 225.01f;  // 15 A cutoff + slack for the f32 box arithmetic
+// Everything inside the kernel lives in coordinates scaled by 2: (2a - 2b)^2 = 4 (a - b)^2 holds
+// bit for bit in IEEE arithmetic (power-of-two scaling commutes with rounding), so
+// D = 4 * d2 exactly, the cutoff d2 <= 225 is D <= 900, and DFIRE's 0.25 A^2 binning cell is
+// simply (int)D -- one conversion, no multiply.
+constexpr double kCutScaled = 900.0;       // 4 * 15^2, src/dfire.rs:334
+constexpr float kCut2Padded = 900.04f;     // the same for the f32 box tests, padded for their rounding
 
 __device__ __forceinline__ float round_down(double v) {
     float f = (float)v;
@@ -126,14 +131,14 @@ __global__ __launch_bounds__(64) void dfire_prepare_receptor(const PrepareRecept
             z += m[2 * pad + a] * c;
         }
     }
-    TiledAtom r;
-    r.x = x;
-    r.y = y;
-    r.z = z;
+    TiledAtom r;  // records carry 2*x, 2*y, 2*z (exact), see "scaled coordinates" in the header comment
+    r.x = 2.0 * x;
+    r.y = 2.0 * y;
+    r.z = 2.0 * z;
     r.tindex = P.tindex[a];
     r.slot = P.slot[a];
     P.atoms_out[pose * pad + a] = r;
-    BoxRegs b = point_box(a < P.n_real, x, y, z);
+    BoxRegs b = point_box(a < P.n_real, r.x, r.y, r.z);
     box_butterfly<1, 8>(b);
     if ((lane & 7) == 0) P.sub_out[(pose * (size_t)P.n_tiles + tile) * 8 + (lane >> 3)] = to_box(b);
     box_butterfly<8, 64>(b);
@@ -144,25 +149,45 @@ __global__ __launch_bounds__(64) void dfire_prepare_receptor(const PrepareRecept
 // Pair kernel
 // ---------------------------------------------------------------------------------------------
 struct PairCtx {
-    const uint8_t *lut;
-    const double *bin_step;
-    const double *tab;  // table + ligand column base of this lane's ligand atom
-    double iface_d2;
+    const uint8_t *lut;      // cell -> bin | 0x40 (pair may be "interface") | 0x80 (a bin step falls inside the cell)
+    const double *bin_step;  // scaled by 4
+    double iface_scaled;     // 4 * iface_d2
     uint32_t *pose_flags;
     int rec_flag_words;
 };
 
-// distance bin of an in-cutoff d2 (src/dfire.rs:336-337) through the exact cell LUT
-__device__ __forceinline__ uint32_t dfire_bin(const PairCtx &c, double d2) {
-    const uint32_t code = c.lut[(int)(fmin(d2, 225.0) * 4.0)];
-    uint32_t bin = code & 0x7fu;
-    if (code & 0x80u) bin += d2 >= c.bin_step[bin + 1] ? 1u : 0u;  // a bin step falls inside this cell
-    return bin;
+// 16-byte halves of a record: two ds_read_b128 per record
+struct alignas(16) RecLo {
+    double x, y;
+};
+struct alignas(16) RecHi {
+    double z;
+    uint32_t tindex;
+    int32_t slot;
+};
+typedef double vec2d __attribute__((ext_vector_type(2)));
+typedef float vec4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void read_record(const TiledAtom *p, RecLo &lo, RecHi &hi) {
+    // two 16-byte vector loads (ds_read_b128 each; member-wise loads become the slower ds_read2_b64)
+    const vec2d a = *reinterpret_cast<const vec2d *>(p);
+    const vec2d b = *reinterpret_cast<const vec2d *>(reinterpret_cast<const unsigned char *>(p) + 16);
+    lo.x = a.x;
+    lo.y = a.y;
+    hi.z = b.x;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(b.y);
+    hi.tindex = (uint32_t)bits;
+    hi.slot = (int32_t)(bits >> 32);
 }
-__device__ __forceinline__ void mark_interface(const PairCtx &c, const TiledAtom &L, const TiledAtom &R) {
-    // d <= 3.9 (src/dfire.rs:339-342); only restraint atoms / membrane beads carry a slot
-    if (R.slot >= 0) atomicOr(&c.pose_flags[R.slot >> 5], 1u << (R.slot & 31));
-    if (L.slot >= 0) atomicOr(&c.pose_flags[c.rec_flag_words + (L.slot >> 5)], 1u << (L.slot & 31));
+
+// the rare tail of a pair: exact position of a bin step inside the cell, interface flags
+__device__ __forceinline__ uint32_t pair_slow_path(const PairCtx &c, uint32_t code, double D, int32_t lslot, int32_t rslot) {
+    uint32_t bin = code & 0x1fu;
+    if (code & 0x80u) bin += D >= c.bin_step[bin + 1] ? 1u : 0u;
+    if ((code & 0x40u) && D <= c.iface_scaled) {  // d <= 3.9 (src/dfire.rs:339-342)
+        if (rslot >= 0) atomicOr(&c.pose_flags[rslot >> 5], 1u << (rslot & 31));
+        if (lslot >= 0) atomicOr(&c.pose_flags[c.rec_flag_words + (lslot >> 5)], 1u << (lslot & 31));
+    }
+    return bin;
 }
 
 template <bool COUNT>
@@ -188,13 +213,13 @@ __global__ __launch_bounds__(1024) void dfire_tiled_pairs(const TiledLaunch T) {
 
     for (int i = tid; i < kDfireLutCells / 4; i += blockDim.x)
         reinterpret_cast<uint32_t *>(lut)[i] = reinterpret_cast<const uint32_t *>(T.lut)[i];
-    if (tid < kDfireSteps) bin_step[tid] = T.bin_step[tid];
+    if (tid < kDfireSteps) bin_step[tid] = 4.0 * T.bin_step[tid];  // scaled coordinates
     __syncthreads();
 
     TiledAtom *ligt = slices + wave * 128;
     TiledAtom *rect = ligt + 64;
     const int li = lane >> 3, lj = lane & 7;
-    double acc = 0.0;
+    double acc = 0.0, pend0 = 0.0, pend1 = 0.0;
     uint32_t cnt = 0, tested = 0;
 
     const int LT = group * T.waves + wave;
@@ -226,9 +251,9 @@ __global__ __launch_bounds__(1024) void dfire_tiled_pairs(const TiledLaunch T) {
                     pz += m[2 * pad + la] * c;
                 }
             }
-            me.x = valid ? px : 1.0e30;  // padding: far away, on the other side of the receptor's padding
-            me.y = valid ? py : 0.0;
-            me.z = valid ? pz : 0.0;
+            me.x = valid ? 2.0 * px : 1.0e30;  // padding: far away, on the other side of the receptor's padding
+            me.y = valid ? 2.0 * py : 0.0;
+            me.z = valid ? 2.0 * pz : 0.0;
             me.tindex = T.lig.tindex[la];
             me.slot = T.lig.slot[la];
         }
@@ -241,8 +266,7 @@ __global__ __launch_bounds__(1024) void dfire_tiled_pairs(const TiledLaunch T) {
         PairCtx ctx;
         ctx.lut = lut;
         ctx.bin_step = bin_step;
-        ctx.tab = T.table;
-        ctx.iface_d2 = T.iface_d2;
+        ctx.iface_scaled = 4.0 * T.iface_d2;
         ctx.pose_flags = T.flags + pose * (size_t)(T.rec.flag_words + T.lig.flag_words);
         ctx.rec_flag_words = T.rec.flag_words;
 
@@ -256,19 +280,30 @@ __global__ __launch_bounds__(1024) void dfire_tiled_pairs(const TiledLaunch T) {
             // ---- 3. stream the surviving tiles; the next tile's loads fly while this one is processed
             int RT = base + __ffsll(rtmask) - 1;
             rtmask &= rtmask - 1;
-            TiledAtom next_atom = rec_atoms[(size_t)RT * 64 + lane];
-            TiledBox next_box = rec_sub[(size_t)RT * 8 + lj];
+            // prefetch registers are plain 16-byte vectors (a struct here ends up in scratch)
+            const vec2d *src = reinterpret_cast<const vec2d *>(rec_atoms + (size_t)RT * 64 + lane);
+            const vec4f *bsrc = reinterpret_cast<const vec4f *>(rec_sub + (size_t)RT * 8 + lj);
+            vec2d next_a0 = src[0], next_a1 = src[1];
+            vec4f next_lo = bsrc[0], next_hi = bsrc[1];
             for (;;) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // reads of the previous tile are done
-                rect[lane] = next_atom;
-                const bool sub_near = box_gap2(sub, next_box) <= kCut2Padded;  // ligand subtile li x receptor subtile lj
+                reinterpret_cast<vec2d *>(rect + lane)[0] = next_a0;
+                reinterpret_cast<vec2d *>(rect + lane)[1] = next_a1;
+                TiledBox nb;
+                nb.lox = next_lo.x; nb.loy = next_lo.y; nb.loz = next_lo.z; nb.pad0 = 0.f;
+                nb.hix = next_hi.x; nb.hiy = next_hi.y; nb.hiz = next_hi.z; nb.pad1 = 0.f;
+                const bool sub_near = box_gap2(sub, nb) <= kCut2Padded;  // ligand subtile li x receptor subtile lj
                 unsigned long long smask = __ballot(sub_near);
                 const bool more = rtmask != 0;
                 if (more) {
                     RT = base + __ffsll(rtmask) - 1;
                     rtmask &= rtmask - 1;
-                    next_atom = rec_atoms[(size_t)RT * 64 + lane];
-                    next_box = rec_sub[(size_t)RT * 8 + lj];
+                    src = reinterpret_cast<const vec2d *>(rec_atoms + (size_t)RT * 64 + lane);
+                    bsrc = reinterpret_cast<const vec4f *>(rec_sub + (size_t)RT * 8 + lj);
+                    next_a0 = src[0];
+                    next_a1 = src[1];
+                    next_lo = bsrc[0];
+                    next_hi = bsrc[1];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // rect/ligt written before anyone reads
                 if (COUNT) tested += (uint32_t)__popcll(smask);
@@ -278,33 +313,64 @@ __global__ __launch_bounds__(1024) void dfire_tiled_pairs(const TiledLaunch T) {
                     const int a = (__ffsll(smask) - 1) >> 3;
                     uint32_t am = (uint32_t)(smask >> (8 * a)) & 0xffu;
                     smask &= ~(0xffull << (8 * a));
-                    const TiledAtom L = ligt[a * 8 + li];
-                    const double *tab = ctx.tab + L.tindex;
+                    RecLo Llo;
+                    RecHi Lhi;
+                    read_record(&ligt[a * 8 + li], Llo, Lhi);
+                    const double *tab = T.table + Lhi.tindex;
                     while (am) {
                         const int b0 = __ffs(am) - 1;
                         am &= am - 1;
-                        const bool two = am != 0;
-                        const int b1 = two ? __ffs(am) - 1 : b0;
-                        am &= am - 1;  // am == 0 stays 0
-                        const TiledAtom R0 = rect[b0 * 8 + lj];
-                        const TiledAtom R1 = rect[b1 * 8 + lj];
-                        // (x1 - la[0])^2 + (y1 - la[1])^2 + (z1 - la[2])^2, src/dfire.rs:331-333
-                        const double dx0 = R0.x - L.x, dy0 = R0.y - L.y, dz0 = R0.z - L.z;
-                        const double dx1 = R1.x - L.x, dy1 = R1.y - L.y, dz1 = R1.z - L.z;
-                        const double d20 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
-                        const double d21 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
-                        const bool hit0 = d20 <= 225.0;
-                        const bool hit1 = two && d21 <= 225.0;
-                        const uint32_t bin0 = dfire_bin(ctx, d20);
-                        const uint32_t bin1 = dfire_bin(ctx, d21);
-                        double v0 = 0.0, v1 = 0.0;
-                        if (hit0) v0 = tab[R0.tindex + bin0];  // src/dfire.rs:338
-                        if (hit1) v1 = tab[R1.tindex + bin1];
-                        acc += v0;
-                        acc += v1;
-                        if (COUNT) cnt += (hit0 ? 1u : 0u) + (hit1 ? 1u : 0u);
-                        if (hit0 && d20 <= ctx.iface_d2) mark_interface(ctx, L, R0);
-                        if (hit1 && d21 <= ctx.iface_d2) mark_interface(ctx, L, R1);
+                        if (am != 0) {
+                            // ---- two subtile pairs of this ligand row in flight ----
+                            const int b1 = __ffs(am) - 1;
+                            am &= am - 1;
+                            RecLo R0lo, R1lo;
+                            RecHi R0hi, R1hi;
+                            read_record(&rect[b0 * 8 + lj], R0lo, R0hi);
+                            read_record(&rect[b1 * 8 + lj], R1lo, R1hi);
+                            // (x1 - la[0])^2 + (y1 - la[1])^2 + (z1 - la[2])^2, src/dfire.rs:331-333 (x4)
+                            const double dx0 = R0lo.x - Llo.x, dy0 = R0lo.y - Llo.y, dz0 = R0hi.z - Lhi.z;
+                            const double dx1 = R1lo.x - Llo.x, dy1 = R1lo.y - Llo.y, dz1 = R1hi.z - Lhi.z;
+                            const double D0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
+                            const double D1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
+                            const bool hit0 = D0 <= kCutScaled, hit1 = D1 <= kCutScaled;
+                            // an out-of-cutoff lane reads past the LUT: LDS returns garbage we never use
+                            const uint32_t code0 = lut[min((unsigned)(int)D0, 903u)];
+                            const uint32_t code1 = lut[min((unsigned)(int)D1, 903u)];
+                            uint32_t bin0 = code0 & 0x1fu, bin1 = code1 & 0x1fu;
+                            const bool slow0 = hit0 && (code0 & 0xc0u), slow1 = hit1 && (code1 & 0xc0u);
+                            if (__builtin_expect(slow0 || slow1, 0)) {
+                                if (slow0) bin0 = pair_slow_path(ctx, code0, D0, Lhi.slot, R0hi.slot);
+                                if (slow1) bin1 = pair_slow_path(ctx, code1, D1, Lhi.slot, R1hi.slot);
+                            }
+                            // retire the previous gathers one iteration late (their L2 latency hides
+                            // behind this iteration's arithmetic); the asm pins "add, then new load"
+                            acc += pend0;
+                            acc += pend1;
+                            asm volatile("" : "+v"(acc) : : "memory");
+                            pend0 = 0.0;
+                            pend1 = 0.0;
+                            if (hit0) pend0 = tab[R0hi.tindex + bin0];  // src/dfire.rs:338
+                            if (hit1) pend1 = tab[R1hi.tindex + bin1];
+                            if (COUNT) cnt += (hit0 ? 1u : 0u) + (hit1 ? 1u : 0u);
+                        } else {
+                            // ---- odd one out ----
+                            RecLo R0lo;
+                            RecHi R0hi;
+                            read_record(&rect[b0 * 8 + lj], R0lo, R0hi);
+                            const double dx0 = R0lo.x - Llo.x, dy0 = R0lo.y - Llo.y, dz0 = R0hi.z - Lhi.z;
+                            const double D0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
+                            const bool hit0 = D0 <= kCutScaled;
+                            const uint32_t code0 = lut[min((unsigned)(int)D0, 903u)];
+                            uint32_t bin0 = code0 & 0x1fu;
+                            const bool slow0 = hit0 && (code0 & 0xc0u);
+                            if (__builtin_expect(slow0, 0)) bin0 = pair_slow_path(ctx, code0, D0, Lhi.slot, R0hi.slot);
+                            acc += pend0;
+                            asm volatile("" : "+v"(acc) : : "memory");
+                            pend0 = 0.0;
+                            if (hit0) pend0 = tab[R0hi.tindex + bin0];
+                            if (COUNT) cnt += hit0 ? 1u : 0u;
+                        }
                     }
                 }
                 if (!more) break;
@@ -313,6 +379,8 @@ __global__ __launch_bounds__(1024) void dfire_tiled_pairs(const TiledLaunch T) {
     }
 
     // ---- 5. reduction ----------------------------------------------------------------------------
+    acc += pend0;
+    acc += pend1;
     acc = wave_sum(acc);
     if (COUNT) cnt = wave_sum_u32(cnt);
     if (lane == 0) {

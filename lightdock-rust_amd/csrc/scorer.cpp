@@ -357,12 +357,15 @@ void Scorer::build_tiled(const ld_scorer_desc &desc) {
     tiled_.bin_step = pair_.bin_step;
     tiled_.iface_d2 = pair_.iface_d2;
     {   // cell code = bin at the cell's lower edge | 0x80 when a bin step falls inside the cell
+        // | 0x40 when the cell reaches below the interface distance (src/dfire.rs:339)
         const DfireBinning b = build_dfire_binning();
         std::vector<uint8_t> code(b.lut);
         for (int c = 0; c <= 900; c++) {
             const int bin = b.lut[c];
             if (b.step[bin + 1] < (c + 1) * 0.25) code[c] |= 0x80u;
+            if (c * 0.25 <= pair_.iface_d2) code[c] |= 0x40u;
         }
+        for (int c = 901; c < kDfireLutCells; c++) code[c] = 0;
         tiled_.lut = arena_.upload(code);
     }
     int waves = 4;  // measured on MI355X (1k4c, 1ppe): 4 waves per workgroup beat 1, 2 and 8
