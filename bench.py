@@ -76,6 +76,20 @@ def cpu_baseline(case, table, poses, budget_s, threads):
             "sample": "%d of the bench poses, %d threads, %.1f s wall (C oracle -O2, f64, no SIMD intrinsics)" % (n, threads, dt)}, out
 
 
+def measured_traffic(args, info):
+    """HBM bytes per pair-kernel launch from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE / WRITE_SIZE collected in separate runs of this same command; see
+    profiles/README.md for the unit and gfx950 corrections).  None when no profile matches the
+    workload, batch and kernel of this run."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    key = "%s:%d:%s" % (args.workload, args.batch, info["pair_kernel_name"])
+    return t.get(key, {}).get("hbm_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,29 +141,22 @@ def main():
     p_cut = d_cnt.cpu().numpy().astype(np.int64)
     algo_bytes_launch = float(info["stream_bytes_per_pose"] * args.batch + 8 * p_cut.sum())
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    multi = pkg.multi
     for _ in range(args.warmup):
         step()
-    barrier()
+    torch.cuda.synchronize()
     scorer.enable_timing(True)
     scorer.pair_kernel_time()          # reset
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+
+    def timed():
+        for _ in range(args.steps):
+            step()
+
+    # barrier + synchronize on both sides, MAX over ranks (multi.timed_region)
+    elapsed = multi.timed_region(timed, dist, sync=torch.cuda.synchronize)
     kern_ms, launches = scorer.pair_kernel_time()
     scorer.enable_timing(False)
     energies = d_out.cpu().numpy()
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     if rank == 0:
         total = args.batch * args.steps * world
@@ -165,7 +172,7 @@ def main():
                        "poses_per_step_per_gpu": args.batch, "pair_tests_per_pose": info["pair_tests_per_pose"],
                        "mean_pairs_in_cutoff": float(p_cut.mean()), "parallelism": "swarm-sharded x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, info),
                          "kernel": info["pair_kernel_name"], "kernel_ms": 1e3 * kern_s,
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "pair_tests_per_s": info["pair_tests_per_pose"] * args.batch / kern_s},

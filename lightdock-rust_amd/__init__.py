@@ -405,4 +405,4 @@ def cli_main(argv):
     return load_library().ld_cli_main(len(args), arr)
 
 
-from . import synth  # noqa: E402,F401
+from . import multi, synth  # noqa: E402,F401

@@ -3,6 +3,7 @@
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace ld {
@@ -35,7 +36,9 @@ Gso::Gso(Scorer &scorer, size_t n_swarms, size_t n_glowworms, const double *posi
     evals_ = arena_.upload(std::vector<unsigned long long>(1, (unsigned long long)total));
 }
 
-Gso::~Gso() {}
+Gso::~Gso() {
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+}
 
 void Gso::step() {
     // Swarm::update_luciferin (src/swarm.rs:66-70): energies only for glowworms that moved
@@ -64,6 +67,48 @@ void Gso::step() {
 }
 
 void Gso::run(uint32_t steps) {
+    // A step is 4 short launches (flag memset, K1, tail, K2); for a single small swarm the
+    // launches, not the kernels, set the pace.  Capture two steps (the pose buffers ping-pong)
+    // into a hipGraph once and replay it.
+    const char *env = std::getenv("LIGHTDOCK_GSO_GRAPH");
+    const bool want_graph = !(env && std::strcmp(env, "0") == 0);
+    if (want_graph && steps >= 6 && !(scorer_.use_anm() && scorer_.anm_rec() > 0)) {
+        if (!graph_exec_) {
+            step();  // eager once: every workspace reaches its final size
+            steps--;
+            hipStream_t st = scorer_.stream();
+            hipGraph_t graph = nullptr;
+            scorer_.set_capturing(true);
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                const uint32_t before = steps_done_;
+                try {
+                    step();
+                    step();
+                } catch (const Error &) {
+                    ok = false;
+                }
+                steps_done_ = before;  // nothing ran yet
+                if (hipStreamEndCapture(st, &graph) != hipSuccess) ok = false;
+            }
+            scorer_.set_capturing(false);
+            if (ok && graph && hipGraphInstantiate(&graph_exec_, graph, nullptr, nullptr, 0) != hipSuccess) graph_exec_ = nullptr;
+            graph_cur_ = cur_;  // the captured pair of steps starts from this pose buffer
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+        }
+        if (graph_exec_ && cur_ != graph_cur_ && steps > 0) {  // an odd number of eager steps since the capture
+            step();
+            steps--;
+        }
+        if (graph_exec_) {
+            while (steps >= 2) {
+                hip_check(hipGraphLaunch(graph_exec_, scorer_.stream()), "hipGraphLaunch");
+                steps_done_ += 2;
+                steps -= 2;
+            }
+        }
+    }
     for (uint32_t s = 0; s < steps; s++) step();
 }
 

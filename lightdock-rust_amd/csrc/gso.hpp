@@ -43,6 +43,8 @@ class Gso {
     int32_t *n_neighbors_ = nullptr, *target_ = nullptr;
     uint32_t *step_ = nullptr, *rng_key_ = nullptr;
     unsigned long long *evals_ = nullptr;
+    hipGraphExec_t graph_exec_ = nullptr;  // two captured steps (even + odd pose buffer)
+    int graph_cur_ = 0;
 };
 
 }  // namespace ld

@@ -191,9 +191,14 @@ int cli_main(int argc, char **argv) {
     Gso gso(scorer, 1, positions.rows, rows.data(), &seed);
     std::printf("Starting optimization (%u steps)\n", steps);
     std::fflush(stdout);
-    for (uint32_t step = 1; step <= steps; step++) {  // GSO::run, src/lib.rs:46-58
-        gso.step();
-        if (step % 10 == 0 || step == 1) gso.save(0, step, swarm_directory);
+    // GSO::run, src/lib.rs:46-58: save after step 1 and after every 10th step; the steps in
+    // between run back to back on the device (hipGraph replay)
+    uint32_t done = 0;
+    while (done < steps) {
+        uint32_t next = done == 0 ? 1 : std::min(steps, (done / 10 + 1) * 10);
+        gso.run(next - done);
+        done = next;
+        if (done % 10 == 0 || done == 1) gso.save(0, done, swarm_directory);
     }
     hip_check(hipStreamSynchronize(scorer.stream()), "hipStreamSynchronize");
     return 0;

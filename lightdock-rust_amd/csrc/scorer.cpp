@@ -243,6 +243,11 @@ Scorer::Scorer(const ld_scorer_desc &desc) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("LIGHTDOCK_ALLOW_ANY_ARCH"))
         throw Error(LD_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
 
+    // own non-blocking stream: kernels of this handle never serialise with the legacy default
+    // stream, and the GSO loop can be captured into a hipGraph
+    hip_check(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking), "hipStreamCreate");
+    stream_ = own_stream_;
+
     std::vector<uint32_t> rgo, rgs, rms, lgo, lgs, lms;
     upload_molecule(desc.receptor, true, pair_.rec, host_rec_, rgo, rgs, rms);
     upload_molecule(desc.ligand, false, pair_.lig, host_lig_, lgo, lgs, lms);
@@ -420,6 +425,10 @@ Scorer::~Scorer() {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    if (own_stream_) {
+        (void)hipStreamSynchronize(own_stream_);
+        (void)hipStreamDestroy(own_stream_);
+    }
     ws_partial_.release();
     ws_flags_.release();
     ws_counts_.release();
@@ -460,7 +469,8 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
 
     const size_t words = (size_t)(p.rec.flag_words + p.lig.flag_words);
     if (words > 0) hip_check(hipMemsetAsync(p.flags, 0, n * words * sizeof(uint32_t), stream_), "hipMemsetAsync(flags)");
-    if (timing_) {
+    const bool timing = timing_ && !capturing_;
+    if (timing) {
         if (events_used_ == events_.size()) {
             if (events_.size() >= 4096) {  // fold what is pending so the pool stays bounded
                 double ms;
@@ -509,7 +519,7 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
     } else {
         hip_check(launch_pair_kernel(p, stream_), "launch pose_energy_pairs");
     }
-    if (timing_) {
+    if (timing) {
         hip_check(hipEventRecord(events_[events_used_].second, stream_), "hipEventRecord");
         events_used_++;
     }

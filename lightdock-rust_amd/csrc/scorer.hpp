@@ -78,7 +78,10 @@ class Scorer {
     const HostMolecule &host_molecule(int side) const { return side ? host_lig_ : host_rec_; }
     int device() const { return device_; }
     hipStream_t stream() const { return stream_; }
-    void set_stream(hipStream_t s) { stream_ = s; }
+    void set_stream(hipStream_t s) { stream_ = s ? s : own_stream_; }  // NULL: back to the handle's own stream
+    void set_capturing(bool on) { capturing_ = on; }
+    // make sure no allocation happens in the next energy_batch_device call of this size
+    void prepare_batch(size_t n_poses) { reserve_workspace(n_poses, false); }
 
     // Enqueue K1 for n poses already in HBM.  active / pair_counts may be null.
     void energy_batch_device(size_t n, const double *d_poses, size_t stride, const uint8_t *d_active,
@@ -111,6 +114,8 @@ class Scorer {
 
     int device_ = 0;
     hipStream_t stream_ = nullptr;
+    hipStream_t own_stream_ = nullptr;
+    bool capturing_ = false;
     int method_ = 0;
     bool use_anm_ = false;
     DeviceArena arena_;

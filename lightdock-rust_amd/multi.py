@@ -1,0 +1,91 @@
+"""Sharding of independent swarms / pose batches over ranks (one process per GPU).
+
+Swarms never exchange data in the reference: every swarm is its own OS process with its own
+input file and output directory (lightdock-rust src/bin/lightdock-rust.rs:171-188; the task
+lists of example/1czy/execution.sh:20-24).  So multi-GPU is pure sharding: rank r owns swarms
+``r, r + W, r + 2W, ...``; the only cross-rank operations are a barrier / max-reduction for
+timing and an optional gather of small per-swarm summaries to rank 0.  No data-path
+collective exists or is needed.
+
+The functions take a ``torch.distributed``-like module (or None for a single process) so the
+same code runs under RCCL on GPUs and under gloo in the CPU tests.
+"""
+import time
+
+
+def world(dist):
+    if dist is None or not dist.is_initialized():
+        return 0, 1
+    return dist.get_rank(), dist.get_world_size()
+
+
+def shard(n_items, rank, world_size):
+    """Indices owned by `rank`: strided, so every rank gets floor or ceil of n/W items."""
+    return list(range(rank, n_items, world_size))
+
+
+def gather_by_swarm(local_results, n_swarms, dist):
+    """local_results: {swarm_id: small picklable summary}.  Returns the list ordered by swarm id
+    on rank 0 (None elsewhere).  Host-side object gather; a few bytes per swarm."""
+    rank, size = world(dist)
+    if size == 1:
+        merged = dict(local_results)
+    else:
+        buckets = [None] * size if rank == 0 else None
+        dist.gather_object(dict(local_results), buckets, dst=0)
+        if rank != 0:
+            return None
+        merged = {}
+        for b in buckets:
+            overlap = set(b) & set(merged)
+            if overlap:
+                raise RuntimeError("swarms evaluated twice: %s" % sorted(overlap))
+            merged.update(b)
+    missing = [s for s in range(n_swarms) if s not in merged]
+    if missing:
+        raise RuntimeError("swarms not evaluated: %s" % missing[:8])
+    return [merged[s] for s in range(n_swarms)]
+
+
+def timed_region(fn, dist, sync=None):
+    """barrier + sync, run fn, barrier + sync; returns the MAX over ranks of the wall time."""
+    rank, size = world(dist)
+
+    def fence():
+        if sync is not None:
+            sync()
+        if size > 1:
+            dist.barrier()
+        if sync is not None:
+            sync()
+
+    fence()
+    t0 = time.perf_counter()
+    fn()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if size > 1:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def run_swarms(make_gso, n_swarms, steps, dist, summarize):
+    """Run `n_swarms` independent swarms sharded over the ranks.
+
+    make_gso(swarm_ids) -> object with .step() and whatever `summarize(gso, local_index, swarm_id)`
+    reads; one batched GSO per rank over the swarms it owns."""
+    rank, size = world(dist)
+    mine = shard(n_swarms, rank, size)
+    results = {}
+    if mine:
+        gso = make_gso(mine)
+        for _ in range(steps):
+            gso.step()
+        for k, s in enumerate(mine):
+            results[s] = summarize(gso, k, s)
+    return gather_by_swarm(results, n_swarms, dist)

@@ -338,3 +338,24 @@ def test_dfire_kernel_variants_agree(pkg, orc, table, scorers, name, env):
     assert np.array_equal(counts[0], counts[1])
     stats = np.array([cpu.energy_ex_row(p)[1][5] for p in poses[:16]])
     assert np.array_equal(counts[0][:16].astype(np.int64), stats.astype(np.int64))
+
+
+def test_gso_run_graph_replay_equals_stepping(pkg, scorers, orc):
+    """ld_gso_run (captured hipGraph, two steps per replay) == ld_gso_step repeated == oracle."""
+    hip, cpu = scorers("1ppe")
+    poses = case_positions("1ppe", orc)
+    a, b = pkg.GSO(hip, poses), pkg.GSO(hip, poses)
+    a.run(25)                 # eager + graph replays + odd tail
+    a.step()                  # odd number of eager steps after the capture ...
+    a.run(9)                  # ... then replay again
+    for _ in range(35):
+        b.step()
+    ref = orc.GSO(cpu, poses)
+    for _ in range(35):
+        ref.step()
+    sa, sb, sr = a.read(0), b.read(0), ref.state()
+    assert a.steps_done == 35 and b.steps_done == 35
+    for k in ("poses", "luciferin", "vision_range", "scoring", "n_neighbors", "target", "moved"):
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(sa["target"], sr["target"]) and np.array_equal(sa["n_neighbors"], sr["n_neighbors"])
+    assert a.num_evals == b.num_evals == ref.num_evals

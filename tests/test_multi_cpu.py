@@ -1,0 +1,85 @@
+"""N > 1 plumbing on CPU: world-size-2 gloo processes shard swarms with no data-path
+collective, and the merged result equals the single-process result.  The work function here
+is the CPU oracle's GSO (tests may use the oracle; the GPU path needs an MI355X)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT, GOLDEN
+
+
+def test_shard_is_a_partition(pkg):
+    from lightdock_rust_amd import multi
+    for n, w in ((1024, 8), (10, 4), (3, 8), (0, 2)):
+        owned = [multi.shard(n, r, w) for r in range(w)]
+        flat = sorted(i for o in owned for i in o)
+        assert flat == list(range(n))
+        sizes = [len(o) for o in owned]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _oracle_swarm_job(orc, pkg, n_swarms, steps):
+    d = os.path.join(GOLDEN, "unit", "1azp")
+    scorer = orc.Scorer("dna", os.path.join(d, "1azp_receptor.pdb"), os.path.join(d, "1azp_ligand.pdb"))
+
+    class Batch:  # a stand-in with the shape of pkg.GSO over several swarms
+        def __init__(self, ids):
+            self.swarms = [orc.GSO(scorer, pkg.synth.swarm(6, seed=s), seed=324324) for s in ids]
+
+        def step(self):
+            for g in self.swarms:
+                g.step()
+
+    def summarize(gso, k, s):
+        st = gso.swarms[k].state()
+        return (s, float(st["scoring"].min()), st["n_neighbors"].tolist())
+
+    return Batch, summarize
+
+
+def _worker(rank, world_size, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    pkg, orc = ge.package(), ge.oracle()
+    from lightdock_rust_amd import multi
+    Batch, summarize = _oracle_swarm_job(orc, pkg, 5, 2)
+    holder = {}
+
+    def job():
+        holder["res"] = multi.run_swarms(Batch, 5, 2, dist, summarize)
+
+    elapsed = multi.timed_region(job, dist)
+    if rank == 0:
+        np.save(out_path, np.array([elapsed] + [r[1] for r in holder["res"]]))
+        assert [r[0] for r in holder["res"]] == list(range(5))
+    else:
+        assert holder["res"] is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one_process(pkg, orc, tmp_path):
+    from lightdock_rust_amd import multi
+    Batch, summarize = _oracle_swarm_job(orc, pkg, 5, 2)
+    single = multi.run_swarms(Batch, 5, 2, None, summarize)
+    out = str(tmp_path / "rank0.npy")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    assert got[0] > 0.0
+    assert np.array_equal(got[1:], np.array([r[1] for r in single]))
+
+
+def test_gather_detects_missing_and_duplicate_swarms(pkg):
+    from lightdock_rust_amd import multi
+    with pytest.raises(RuntimeError, match="not evaluated"):
+        multi.gather_by_swarm({0: "a"}, 2, None)
+    assert multi.gather_by_swarm({1: "b", 0: "a"}, 2, None) == ["a", "b"]
