@@ -190,8 +190,10 @@ __device__ __forceinline__ uint32_t pair_slow_path(const PairCtx &c, uint32_t co
     return bin;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(1024) void dfire_tiled_pairs(const TiledLaunch T) {
+// MAXT/MINW = launch bounds.  Capping registers at 64 (8 waves per SIMD) was measured SLOWER on
+// MI355X (spills + no gain from occupancy: the kernel is bound by L2 gather requests), so MINW = 1.
+template <bool COUNT, int MAXT, int MINW>
+__global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunch T) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // ---- LDS carve (every offset a multiple of 16) ---------------------------------------
     uint8_t *lut = smem;
@@ -426,8 +428,13 @@ hipError_t launch_dfire_tiled(const TiledLaunch &t, hipStream_t stream) {
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     const size_t lds = tiled_kernel_lds_bytes(t);
     const dim3 grid((unsigned)blocks), block((unsigned)t.waves * 64);
-    if (t.count_partial != nullptr) hipLaunchKernelGGL((dfire_tiled_pairs<true>), grid, block, lds, stream, t);
-    else hipLaunchKernelGGL((dfire_tiled_pairs<false>), grid, block, lds, stream, t);
+    if (t.waves <= 4) {
+        if (t.count_partial != nullptr) hipLaunchKernelGGL((dfire_tiled_pairs<true, 256, 1>), grid, block, lds, stream, t);
+        else hipLaunchKernelGGL((dfire_tiled_pairs<false, 256, 1>), grid, block, lds, stream, t);
+    } else {
+        if (t.count_partial != nullptr) hipLaunchKernelGGL((dfire_tiled_pairs<true, 1024, 1>), grid, block, lds, stream, t);
+        else hipLaunchKernelGGL((dfire_tiled_pairs<false, 1024, 1>), grid, block, lds, stream, t);
+    }
     return hipGetLastError();
 }
 
