@@ -28,6 +28,7 @@
 #include "dfire_tiled.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace ld {
 
@@ -167,6 +168,8 @@ struct alignas(16) RecHi {
 };
 typedef double vec2d __attribute__((ext_vector_type(2)));
 typedef float vec4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned int lds_u32;
+typedef __attribute__((address_space(1))) unsigned int global_u32;
 __device__ __forceinline__ void read_record(const TiledAtom *p, RecLo &lo, RecHi &hi) {
     // two 16-byte vector loads (ds_read_b128 each; member-wise loads become the slower ds_read2_b64)
     const vec2d a = *reinterpret_cast<const vec2d *>(p);
@@ -279,34 +282,21 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
             unsigned long long rtmask = __ballot(tile_near);
             if (rtmask == 0) continue;
 
-            // ---- 3. stream the surviving tiles; the next tile's loads fly while this one is processed
-            int RT = base + __ffsll(rtmask) - 1;
-            rtmask &= rtmask - 1;
-            // prefetch registers are plain 16-byte vectors (a struct here ends up in scratch)
-            const vec2d *src = reinterpret_cast<const vec2d *>(rec_atoms + (size_t)RT * 64 + lane);
-            const vec4f *bsrc = reinterpret_cast<const vec4f *>(rec_sub + (size_t)RT * 8 + lj);
-            vec2d next_a0 = src[0], next_a1 = src[1];
-            vec4f next_lo = bsrc[0], next_hi = bsrc[1];
-            for (;;) {
+            // ---- 3. stream the surviving tiles through the LDS slice
+            while (rtmask) {
+                const int RT = base + __ffsll(rtmask) - 1;
+                rtmask &= rtmask - 1;
+                // 2 KiB of records straight from L2/HBM into this wave's LDS slice (LDS-DMA: no
+                // VGPRs, no ds_write); lane l moves bytes [16 l, 16 l + 16) of each KiB
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // reads of the previous tile are done
-                reinterpret_cast<vec2d *>(rect + lane)[0] = next_a0;
-                reinterpret_cast<vec2d *>(rect + lane)[1] = next_a1;
-                TiledBox nb;
-                nb.lox = next_lo.x; nb.loy = next_lo.y; nb.loz = next_lo.z; nb.pad0 = 0.f;
-                nb.hix = next_hi.x; nb.hiy = next_hi.y; nb.hiz = next_hi.z; nb.pad1 = 0.f;
+                const unsigned char *gsrc = reinterpret_cast<const unsigned char *>(rec_atoms + (size_t)RT * 64) + lane * 16;
+                __builtin_amdgcn_global_load_lds((const global_u32 *)gsrc, (lds_u32 *)rect, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const global_u32 *)(gsrc + 1024),
+                                                 (lds_u32 *)(reinterpret_cast<unsigned char *>(rect) + 1024), 16, 0, 0);
+                const TiledBox nb = rec_sub[(size_t)RT * 8 + lj];
                 const bool sub_near = box_gap2(sub, nb) <= kCut2Padded;  // ligand subtile li x receptor subtile lj
                 unsigned long long smask = __ballot(sub_near);
-                const bool more = rtmask != 0;
-                if (more) {
-                    RT = base + __ffsll(rtmask) - 1;
-                    rtmask &= rtmask - 1;
-                    src = reinterpret_cast<const vec2d *>(rec_atoms + (size_t)RT * 64 + lane);
-                    bsrc = reinterpret_cast<const vec4f *>(rec_sub + (size_t)RT * 8 + lj);
-                    next_a0 = src[0];
-                    next_a1 = src[1];
-                    next_lo = bsrc[0];
-                    next_hi = bsrc[1];
-                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA has landed
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // rect/ligt written before anyone reads
                 if (COUNT) tested += (uint32_t)__popcll(smask);
 
@@ -375,7 +365,6 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
                         }
                     }
                 }
-                if (!more) break;
             }
         }
     }
@@ -419,6 +408,7 @@ size_t tiled_kernel_lds_bytes(const TiledLaunch &t) {
     size_t b = ((kDfireLutCells + 15) & ~15) + kDfireSteps * sizeof(double);
     b += kTiledMaxWaves * sizeof(double) + kTiledMaxWaves * 2 * sizeof(uint32_t);
     b += (size_t)t.waves * 128 * sizeof(TiledAtom);
+    if (const char *e = getenv("LIGHTDOCK_TILED_LDS_PAD")) b += (size_t)atoi(e);  // occupancy experiments
     return b;
 }
 
