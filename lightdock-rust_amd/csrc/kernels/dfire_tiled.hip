@@ -212,8 +212,15 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t pose = blockIdx.x / (unsigned)T.n_groups;
-    const int group = blockIdx.x % (unsigned)T.n_groups;
+    // Block id -> (pose, group) through a multiplicative permutation.  The ligand tiles at the
+    // interface carry most of the work; the hardware deals block ids round-robin to XCDs and
+    // CUs, and with the plain pose-major order throughput swung by +-20 % with the parity of
+    // groups-per-pose (the same heavy group index kept landing on the same XCDs/CUs).  Scattering
+    // the items gives every XCD and CU the same mix of heavy and light workgroups at all times.
+    const unsigned long long total_items = (unsigned long long)T.n_poses * (unsigned)T.n_groups;
+    const unsigned long long item_id = ((unsigned long long)blockIdx.x * 2654435761ull) % total_items;  // prime > total: a bijection
+    const size_t pose = (size_t)(item_id / (unsigned)T.n_groups);
+    const int group = (int)(item_id % (unsigned)T.n_groups);
     if (T.active != nullptr && T.active[pose] == 0) return;
 
     for (int i = tid; i < kDfireLutCells / 4; i += blockDim.x)
@@ -227,7 +234,11 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
     double acc = 0.0, pend0 = 0.0, pend1 = 0.0;
     uint32_t cnt = 0, tested = 0;
 
-    const int LT = group * T.waves + wave;
+    // work item = (ligand tile, part): `split` waves share one ligand tile and take every
+    // split-th surviving receptor tile, so the tiles at the interface do not make one long wave
+    const int item = group * T.waves + wave;
+    const int LT = item / T.split;
+    const int part = item % T.split;
     if (LT < T.lig.n_tiles) {
         const double *row = T.poses + pose * T.stride;
         const TiledAtom *rec_atoms = T.rec.atoms + pose * T.rec.pose_stride_atoms;
@@ -283,9 +294,11 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
             if (rtmask == 0) continue;
 
             // ---- 3. stream the surviving tiles through the LDS slice
+            int turn = 0;
             while (rtmask) {
                 const int RT = base + __ffsll(rtmask) - 1;
                 rtmask &= rtmask - 1;
+                if (turn++ % T.split != part) continue;
                 // 2 KiB of records straight from L2/HBM into this wave's LDS slice (LDS-DMA: no
                 // VGPRs, no ds_write); lane l moves bytes [16 l, 16 l + 16) of each KiB
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // reads of the previous tile are done

@@ -62,7 +62,8 @@ struct TiledLaunch {
     int use_anm = 0;
     int anm_rec = 0;      // pose-row columns taken by receptor ANM extents
     int waves = 1;        // wave64s per workgroup; each wave owns one ligand tile of one pose
-    int n_groups = 0;     // workgroups per pose = ceil(lig.n_tiles / waves)
+    int split = 1;        // waves sharing one ligand tile (each takes every split-th surviving receptor tile)
+    int n_groups = 0;     // workgroups per pose = ceil(lig.n_tiles * split / waves)
     const double *table = nullptr;
     const uint8_t *lut = nullptr;      // cell -> bin | 0x80 if a bin step falls inside the cell
     const double *bin_step = nullptr;  // kDfireSteps

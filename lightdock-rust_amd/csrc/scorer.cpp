@@ -378,8 +378,18 @@ void Scorer::build_tiled(const ld_scorer_desc &desc) {
         int v = std::atoi(e);
         if (v >= 1 && v <= kTiledMaxWaves) waves = v;
     }
+    // Small ligands (few 64-atom tiles) give too few waves per pose: let 3 waves share a tile,
+    // each taking every 3rd surviving receptor tile.  Measured on MI355X: 1ppe (4 tiles) +15 %
+    // with split 3/5/7, 1k4c (52 tiles) best with 1; splits sharing a factor with the 4 waves of
+    // a workgroup (2, 4) are consistently slower, so only odd values are used.
+    int split = tiled_.lig.n_tiles < 32 ? 3 : 1;
+    if (const char *e = std::getenv("LIGHTDOCK_TILED_SPLIT")) {
+        int v = std::atoi(e);
+        if (v >= 1 && v <= 8) split = v;
+    }
     tiled_.waves = waves;
-    tiled_.n_groups = (tiled_.lig.n_tiles + waves - 1) / waves;
+    tiled_.split = split;
+    tiled_.n_groups = (tiled_.lig.n_tiles * split + waves - 1) / waves;
 
     rec_anm_per_pose_ = use_anm_ && tiled_rec_soa_.num_anm > 0;
     if (!rec_anm_per_pose_) {
