@@ -8,7 +8,7 @@ import os
 import sys
 
 out = sys.argv[1]
-KERNEL = "dfire_tiled_pairs<false>"
+KERNEL = "dfire_tiled_pairs<false"
 
 
 def counters(sub):
