@@ -359,3 +359,104 @@ def test_gso_run_graph_replay_equals_stepping(pkg, scorers, orc):
         assert np.array_equal(sa[k], sb[k]), k
     assert np.array_equal(sa["target"], sr["target"]) and np.array_equal(sa["n_neighbors"], sr["n_neighbors"])
     assert a.num_evals == b.num_evals == ref.num_evals
+
+
+def _write_pdb(path, atoms):
+    """atoms: (name, resname, chain, resseq, x, y, z)"""
+    with open(path, "w") as f:
+        for k, (name, res, chain, seq, x, y, z) in enumerate(atoms, 1):
+            f.write("ATOM  %5d  %-3s %3s %1s%4d    %8.3f%8.3f%8.3f  1.00  0.00\n" % (k, name, res, chain, seq, x, y, z))
+
+
+def test_tiny_molecules_and_cutoff_corners(pkg, orc, table, tmp_path):
+    """Edge cases of src/dfire.rs:325-345 on hand-made molecules, every DFIRE kernel variant:
+    r = 15.0 A exactly (inclusive cutoff, reads bin 20 = next row's bin 0), r < 0.5 A (negative d
+    saturates to index 0), an interface pair (d <= 3.9), ligand/receptor far smaller than a tile,
+    a pose that leaves no pair in range (score = 4.7), non-unit quaternions (src/qt.rs:48-50)."""
+    rec = str(tmp_path / "rec.pdb")
+    lig = str(tmp_path / "lig.pdb")
+    _write_pdb(rec, [("N", "ALA", "A", 1, 0.0, 0.0, 0.0), ("CA", "ALA", "A", 1, 1.4, 0.3, 0.0),
+                     ("BJ", "MMB", "C", 9, -3.0, 0.0, 0.0), ("OH", "TYR", "A", 2, 0.0, 4.0, 1.0)])
+    _write_pdb(lig, [("N", "GLY", "B", 1, 15.0, 0.0, 0.0), ("CA", "GLY", "B", 1, 0.05, 0.05, 0.05),
+                     ("SG", "CYS", "B", 2, -3.5, 1.2, 0.0)])
+    poses = np.array([
+        [0, 0, 0, 1, 0, 0, 0],                      # identity: r = 15 exactly for (rec N, lig N)
+        [0, 0, 0, 2.0, 0, 0, 0],                    # same rotation, quaternion of norm 2
+        [100.0, 0, 0, 1, 0, 0, 0],                  # nothing in range
+        [0.5, -0.25, 0.125, 0.5, 0.5, 0.5, 0.5],    # 120 degree rotation about (1,1,1)
+        [1e-3, 0, 0, 0.9, 0.1, -0.3, 0.2],
+    ], dtype=np.float64)
+    cpu = orc.Scorer("dfire", rec, lig, rec_active=["A.TYR.2"], lig_active=["B.CYS.2"], potential=table)
+    e0, st0 = cpu.energy_ex_row(poses[0])
+    assert st0[5] >= 3 and st0[4] > 0            # in-cutoff pairs incl. the r = 15 one; the bead is touched
+    assert cpu.energy_row(poses[2]) == 4.7
+    want = cpu.energy_rows(poses)
+    assert want[0] == want[1]
+    for env in ({}, {"LIGHTDOCK_DFIRE_KERNEL": "allpairs"}, {"LIGHTDOCK_TILED_WAVES": "16", "LIGHTDOCK_TILED_SPLIT": "2"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            hip = pkg.Scorer.from_pdb("dfire", rec, lig, rec_active=["A.TYR.2"], lig_active=["B.CYS.2"], potential=table)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        got = hip.energy_batch(poses)
+        assert rel_err(got, want) < 1e-12, env
+        assert got[2] == 4.7
+
+
+def test_gso_odd_sizes(pkg, scorers, orc):
+    """1 glowworm (never has a neighbour), 3 glowworms, and more glowworms than threads in a
+    workgroup (1030 > 1024): same as the oracle."""
+    hip, cpu = scorers("1ppe")
+    base = case_positions("1ppe", orc)
+    for n, steps in ((1, 3), (3, 5), (1030, 3)):
+        pos = pkg.synth.jitter(base, n, seed=n) if n > 200 else base[:n]
+        gso, ref = pkg.GSO(hip, pos), orc.GSO(cpu, pos)
+        for _ in range(steps):
+            gso.step()
+            ref.step()
+        a, b = gso.read(0), ref.state()
+        assert np.array_equal(a["n_neighbors"], b["n_neighbors"]) and np.array_equal(a["target"], b["target"])
+        assert rel_err(a["luciferin"], b["luciferin"]) < REL_TOL
+        assert np.array_equal(a["vision_range"], b["vision_range"])
+    g = pkg.GSO(hip, base[:4])
+    g.run(0)
+    assert g.steps_done == 0 and g.num_evals == 0
+    st = g.read(0)
+    assert np.all(st["luciferin"] == 5.0) and np.all(st["vision_range"] == 0.2) and np.all(st["moved"] == 0)
+
+
+def test_gso_dfire_with_anm_2uuy(pkg, scorers, orc):
+    """DFIRE with receptor + ligand ANM (per-pose receptor image, src/dfire.rs:304-320) inside
+    the GSO loop, incl. the ANM move step (src/glowworm.rs:159-188)."""
+    hip, cpu = scorers("2uuy")
+    poses = case_positions("2uuy", orc)[:96]
+    gso, ref = pkg.GSO(hip, poses), orc.GSO(cpu, poses)
+    for step in range(12):
+        gso.step()
+        ref.step()
+    a, b = gso.read(0), ref.state()
+    assert np.array_equal(a["n_neighbors"], b["n_neighbors"]) and np.array_equal(a["target"], b["target"])
+    assert rel_err(a["scoring"], b["scoring"]) < REL_TOL
+    assert np.max(np.abs(a["poses"] - b["poses"])) < 1e-12
+
+
+@pytest.mark.timeout(900)
+def test_cli_100_steps_matches_reference_files_1azp(pkg, tmp_path):
+    """The full published run of the example: 100 steps, all 11 gso files against the files the
+    Rust binary wrote (example/1azp/swarm_0)."""
+    src = os.path.join(GOLDEN, "1azp")
+    for f in ("rec_nm.npy", "lig_nm.npy"):
+        shutil.copy(os.path.join(src, f), tmp_path)
+    r = subprocess.run([pkg.CLI_PATH, os.path.join(src, "setup.json"), os.path.join(src, "initial_positions_0.dat"),
+                        "100", "dna"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for step in [1] + list(range(10, 101, 10)):
+        got = parse_gso(os.path.join(tmp_path, "swarm_0", "gso_%d.out" % step))
+        want = parse_gso(os.path.join(src, "swarm_0", "gso_%d.out" % step))
+        assert np.array_equal(got[2], want[2]), "neighbour counts differ at step %d" % step
+        assert np.max(np.abs(got[0] - want[0])) <= 1.01e-7
+        assert np.max(np.abs(got[3] - want[3])) <= 1.01e-3
+        assert np.all(np.abs(got[1] - want[1]) <= 1.01e-8 + 1e-9 * np.abs(want[1]))
+        assert np.all(np.abs(got[4] - want[4]) <= 1.01e-8 + 1e-9 * np.abs(want[4]))
