@@ -314,69 +314,49 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
                 if (COUNT) tested += (uint32_t)__popcll(smask);
 
                 // ---- 4. surviving subtile pairs, one ligand row (a) at a time ------------------
+                // ---- 4. surviving subtile pairs, two at a time (flat over the 8x8 mask) ----------
+                // bit k of smask = (ligand subtile k >> 3, receptor subtile k & 7).  Both blocks of
+                // an iteration are fully independent; an odd leftover is paired with itself and
+                // its second copy masked off (one straight-line body: the deferred gather
+                // retirement below needs no register copies).
                 while (smask) {
-                    const int a = (__ffsll(smask) - 1) >> 3;
-                    uint32_t am = (uint32_t)(smask >> (8 * a)) & 0xffu;
-                    smask &= ~(0xffull << (8 * a));
-                    RecLo Llo;
-                    RecHi Lhi;
-                    read_record(&ligt[a * 8 + li], Llo, Lhi);
-                    const double *tab = T.table + Lhi.tindex;
-                    while (am) {
-                        const int b0 = __ffs(am) - 1;
-                        am &= am - 1;
-                        if (am != 0) {
-                            // ---- two subtile pairs of this ligand row in flight ----
-                            const int b1 = __ffs(am) - 1;
-                            am &= am - 1;
-                            RecLo R0lo, R1lo;
-                            RecHi R0hi, R1hi;
-                            read_record(&rect[b0 * 8 + lj], R0lo, R0hi);
-                            read_record(&rect[b1 * 8 + lj], R1lo, R1hi);
-                            // (x1 - la[0])^2 + (y1 - la[1])^2 + (z1 - la[2])^2, src/dfire.rs:331-333 (x4)
-                            const double dx0 = R0lo.x - Llo.x, dy0 = R0lo.y - Llo.y, dz0 = R0hi.z - Lhi.z;
-                            const double dx1 = R1lo.x - Llo.x, dy1 = R1lo.y - Llo.y, dz1 = R1hi.z - Lhi.z;
-                            const double D0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
-                            const double D1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
-                            const bool hit0 = D0 <= kCutScaled, hit1 = D1 <= kCutScaled;
-                            // an out-of-cutoff lane reads past the LUT: LDS returns garbage we never use
-                            const uint32_t code0 = lut[min((unsigned)(int)D0, 903u)];
-                            const uint32_t code1 = lut[min((unsigned)(int)D1, 903u)];
-                            uint32_t bin0 = code0 & 0x1fu, bin1 = code1 & 0x1fu;
-                            const bool slow0 = hit0 && (code0 & 0xc0u), slow1 = hit1 && (code1 & 0xc0u);
-                            if (__builtin_expect(slow0 || slow1, 0)) {
-                                if (slow0) bin0 = pair_slow_path(ctx, code0, D0, Lhi.slot, R0hi.slot);
-                                if (slow1) bin1 = pair_slow_path(ctx, code1, D1, Lhi.slot, R1hi.slot);
-                            }
-                            // retire the previous gathers one iteration late (their L2 latency hides
-                            // behind this iteration's arithmetic); the asm pins "add, then new load"
-                            acc += pend0;
-                            acc += pend1;
-                            asm volatile("" : "+v"(acc) : : "memory");
-                            pend0 = 0.0;
-                            pend1 = 0.0;
-                            if (hit0) pend0 = tab[R0hi.tindex + bin0];  // src/dfire.rs:338
-                            if (hit1) pend1 = tab[R1hi.tindex + bin1];
-                            if (COUNT) cnt += (hit0 ? 1u : 0u) + (hit1 ? 1u : 0u);
-                        } else {
-                            // ---- odd one out ----
-                            RecLo R0lo;
-                            RecHi R0hi;
-                            read_record(&rect[b0 * 8 + lj], R0lo, R0hi);
-                            const double dx0 = R0lo.x - Llo.x, dy0 = R0lo.y - Llo.y, dz0 = R0hi.z - Lhi.z;
-                            const double D0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
-                            const bool hit0 = D0 <= kCutScaled;
-                            const uint32_t code0 = lut[min((unsigned)(int)D0, 903u)];
-                            uint32_t bin0 = code0 & 0x1fu;
-                            const bool slow0 = hit0 && (code0 & 0xc0u);
-                            if (__builtin_expect(slow0, 0)) bin0 = pair_slow_path(ctx, code0, D0, Lhi.slot, R0hi.slot);
-                            acc += pend0;
-                            asm volatile("" : "+v"(acc) : : "memory");
-                            pend0 = 0.0;
-                            if (hit0) pend0 = tab[R0hi.tindex + bin0];
-                            if (COUNT) cnt += hit0 ? 1u : 0u;
-                        }
+                    const int k0 = __ffsll(smask) - 1;
+                    smask &= smask - 1;
+                    const bool two = smask != 0;
+                    const int k1 = two ? __ffsll(smask) - 1 : k0;
+                    smask &= smask - 1;  // 0 stays 0
+                    RecLo L0lo, L1lo, R0lo, R1lo;
+                    RecHi L0hi, L1hi, R0hi, R1hi;
+                    read_record(&ligt[(k0 >> 3) * 8 + li], L0lo, L0hi);
+                    read_record(&rect[(k0 & 7) * 8 + lj], R0lo, R0hi);
+                    read_record(&ligt[(k1 >> 3) * 8 + li], L1lo, L1hi);
+                    read_record(&rect[(k1 & 7) * 8 + lj], R1lo, R1hi);
+                    // (x1 - la[0])^2 + (y1 - la[1])^2 + (z1 - la[2])^2, src/dfire.rs:331-333 (x4)
+                    const double dx0 = R0lo.x - L0lo.x, dy0 = R0lo.y - L0lo.y, dz0 = R0hi.z - L0hi.z;
+                    const double dx1 = R1lo.x - L1lo.x, dy1 = R1lo.y - L1lo.y, dz1 = R1hi.z - L1hi.z;
+                    const double D0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
+                    const double D1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
+                    const bool hit0 = D0 <= kCutScaled;
+                    const bool hit1 = two && D1 <= kCutScaled;
+                    const uint32_t code0 = lut[min((unsigned)(int)D0, 903u)];
+                    const uint32_t code1 = lut[min((unsigned)(int)D1, 903u)];
+                    uint32_t bin0 = code0 & 0x1fu, bin1 = code1 & 0x1fu;
+                    const bool slow0 = hit0 && (code0 & 0xc0u), slow1 = hit1 && (code1 & 0xc0u);
+                    if (__builtin_expect(slow0 || slow1, 0)) {
+                        if (slow0) bin0 = pair_slow_path(ctx, code0, D0, L0hi.slot, R0hi.slot);
+                        if (slow1) bin1 = pair_slow_path(ctx, code1, D1, L1hi.slot, R1hi.slot);
                     }
+                    // retire the previous iteration's gathers only now, so their L2 latency hides
+                    // behind this iteration's LDS reads and arithmetic; the asm pins the order
+                    // "add the old value, then issue the new load into the same register"
+                    acc += pend0;
+                    acc += pend1;
+                    asm volatile("" : "+v"(acc) : : "memory");
+                    pend0 = 0.0;
+                    pend1 = 0.0;
+                    if (hit0) pend0 = T.table[L0hi.tindex + bin0 * kTiledTableStride + R0hi.tindex];  // src/dfire.rs:338, re-laid out
+                    if (hit1) pend1 = T.table[L1hi.tindex + bin1 * kTiledTableStride + R1hi.tindex];
+                    if (COUNT) cnt += (hit0 ? 1u : 0u) + (hit1 ? 1u : 0u);
                 }
             }
         }

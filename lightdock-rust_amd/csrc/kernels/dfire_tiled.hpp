@@ -15,11 +15,19 @@
 namespace ld {
 
 constexpr int kTiledMaxWaves = 16;
+// The tiled kernel reads the potential as table[lig_type][bin 0..20][rec_type] (stride 176):
+// the 8 receptor atoms of a subtile are mostly one residue, whose DFIRE types are consecutive
+// numbers, so lanes of one ligand atom whose pairs fall in the same distance bin share a 64-byte
+// line.  The kernel is bound by outstanding L1 misses of this gather, so fewer
+// distinct lines per wave instruction is throughput.  Entry [l][20][r] is what the reference
+// reads for r = 15.0 A exactly: potential[r*3380 + l*20 + 20] (src/dfire.rs:338).
+constexpr uint32_t kTiledTableStride = 176;
+constexpr uint32_t kTiledTableBins = 21;
 
 // 32-byte atom record, the unit both molecules are handled in inside the kernel.
 struct alignas(16) TiledAtom {
     double x, y, z;
-    uint32_t tindex;  // receptor: type*3380, ligand: type*20 (src/dfire.rs:338)
+    uint32_t tindex;  // receptor: type, ligand: type * 21 * 176 (see kTiledTableStride)
     int32_t slot;     // interface-flag bit or -1
 };
 static_assert(sizeof(TiledAtom) == 32, "TiledAtom must be 32 bytes");

@@ -315,7 +315,7 @@ void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, Tiled
         x[i] = m.coordinates[3 * (size_t)a];
         y[i] = m.coordinates[3 * (size_t)a + 1];
         z[i] = m.coordinates[3 * (size_t)a + 2];
-        t[i] = m.dfire_types[a] * (is_receptor ? kDfireRowStride : 20u);
+        t[i] = is_receptor ? m.dfire_types[a] : m.dfire_types[a] * kTiledTableBins * kTiledTableStride;
         slot[i] = hslot[a];
     }
     out.n_real = (int)n;
@@ -358,7 +358,14 @@ void Scorer::build_tiled(const ld_scorer_desc &desc) {
     tiled_.rec.flag_words = pair_.rec.flag_words;
     tiled_.use_anm = use_anm_ ? 1 : 0;
     tiled_.anm_rec = (int)anm_rec();
-    tiled_.table = pair_.table;
+    {   // potential re-laid out as [lig type][bin 0..20][rec type], see dfire_tiled.hpp
+        std::vector<double> t2((size_t)169 * kTiledTableBins * kTiledTableStride, 0.0);
+        for (uint32_t l = 0; l < 168; l++)
+            for (uint32_t b = 0; b < kTiledTableBins; b++)
+                for (uint32_t r = 0; r < 168; r++)
+                    t2[((size_t)l * kTiledTableBins + b) * kTiledTableStride + r] = desc.potential[(size_t)r * kDfireRowStride + l * 20 + b];
+        tiled_.table = arena_.upload(t2);
+    }
     tiled_.bin_step = pair_.bin_step;
     tiled_.iface_d2 = pair_.iface_d2;
     {   // cell code = bin at the cell's lower edge | 0x80 when a bin step falls inside the cell
