@@ -40,7 +40,9 @@ typedef enum ld_status {
 } ld_status;
 
 /* src/scoring.rs:5-9 `enum Method` */
-typedef enum ld_method { LD_METHOD_DFIRE = 0, LD_METHOD_DNA = 1 } ld_method;
+/* PYDOCK (src/pydock.rs) is the DNA energy (src/pydock.rs:425-545 == src/dna.rs:411-529) behind a
+ * model builder with a generic-element fallback for unknown atoms (src/pydock.rs:332-345). */
+typedef enum ld_method { LD_METHOD_DFIRE = 0, LD_METHOD_DNA = 1, LD_METHOD_PYDOCK = 2 } ld_method;
 
 #define LD_DFIRE_TABLE_LEN (169 * 169 * 20) /* src/dfire.rs:216,251 */
 
@@ -208,7 +210,7 @@ int ld_gso_save(ld_gso *g, size_t swarm, uint32_t step, const char *dir);
 
 /* ------------------------------------------------------------------------------------
  * The reference command line (src/bin/lightdock-rust.rs:77-333) as a function:
- *   argv = { prog, setup.json, initial_positions_N.dat, steps, dfire|dna }
+ *   argv = { prog, setup.json, initial_positions_N.dat, steps, dfire|dna|pydock }
  * Same stdout lines, same files, same "usage errors return 0" behaviour.
  * ---------------------------------------------------------------------------------- */
 int ld_cli_main(int argc, char **argv);

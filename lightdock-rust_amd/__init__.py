@@ -20,8 +20,9 @@ INCLUDE_DIR = os.path.normpath(os.path.join(_HERE, "..", "include"))
 
 METHOD_DFIRE = 0
 METHOD_DNA = 1
+METHOD_PYDOCK = 2
 DFIRE_TABLE_LEN = 169 * 169 * 20
-METHODS = {"dfire": METHOD_DFIRE, "dna": METHOD_DNA}
+METHODS = {"dfire": METHOD_DFIRE, "dna": METHOD_DNA, "pydock": METHOD_PYDOCK}
 
 
 class LightdockError(RuntimeError):

@@ -94,7 +94,8 @@ ld_scorer *ld_scorer_create_from_pdb(int method, const char *receptor_pdb, const
     ld_scorer *s = nullptr;
     int rc = guarded([&] {
         if (!receptor_pdb || !ligand_pdb) throw ld::Error(LD_ERR_INVALID, "PDB path missing");
-        if (method != LD_METHOD_DFIRE && method != LD_METHOD_DNA) throw ld::Error(LD_ERR_UNSUPPORTED, "Error: method not supported");
+        if (method != LD_METHOD_DFIRE && method != LD_METHOD_DNA && method != LD_METHOD_PYDOCK)
+            throw ld::Error(LD_ERR_UNSUPPORTED, "Error: method not supported");
         ld::Structure rec = ld::read_pdb(receptor_pdb);
         ld::Structure lig = ld::read_pdb(ligand_pdb);
         std::vector<double> rnm, lnm;

@@ -100,7 +100,8 @@ int cli_main(int argc, char **argv) {
     const char *method_name;
     if (method_type == "dfire") { method = LD_METHOD_DFIRE; method_name = "DFIRE"; }
     else if (method_type == "dna") { method = LD_METHOD_DNA; method_name = "DNA"; }
-    else {  // "pydock" is outside this engine's scope
+    else if (method_type == "pydock") { method = LD_METHOD_PYDOCK; method_name = "PYDOCK"; }
+    else {
         std::fprintf(stderr, "Error: method not supported\n");
         return 0;
     }

@@ -94,20 +94,37 @@ uint32_t dfire_atom_type(const std::string &res_name, const std::string &atom_na
     return it->second;
 }
 
-DnaAtomParams dna_atom_params(const std::string &res_name, const std::string &atom_name) {
+DnaAtomParams dna_atom_params(const std::string &res_name, const std::string &atom_name, bool generic_fallback) {
+    const std::string who = generic_fallback ? "PYDOCK" : "DNA";
     std::string key = res_name + "-" + atom_name;
     const DnaRecord *rec = find_dna_record(key);
-    if (!rec && (atom_name == "H1" || atom_name == "H2" || atom_name == "H3")) {
-        key = res_name + "-H";  // N-terminal hydrogens fall back to the backbone amide H
-        rec = find_dna_record(key);
+    if (!rec) {
+        if (atom_name == "H1" || atom_name == "H2" || atom_name == "H3") {
+            key = res_name + "-H";  // N-terminal hydrogens fall back to the backbone amide H
+            rec = find_dna_record(key);
+        } else if (generic_fallback) {
+            // the six generic records PYDOCK adds to the tables: AMBER type = the element, charge below;
+            // well depth / radius are those of that AMBER type (borrowed from a record that has it)
+            static const struct { char element; const char *like; double charge; } kGeneric[] = {
+                {'C', "ALA-C", 0.5973}, {'F', nullptr, -0.342}, {'H', "ALA-H", 0.2719},
+                {'N', "ALA-N", -0.4157}, {'O', "ALA-O", -0.5679}, {'S', "MET-SD", -0.2737}};
+            if (atom_name.empty()) throw Error(LD_ERR_UNSUPPORTED, "PYDOCK Error: Atom element could not be guessed from [\"\"]");
+            key = std::string("*-") + atom_name[0];
+            for (const auto &g : kGeneric) {
+                if (g.element != atom_name[0]) continue;
+                if (g.like == nullptr) return DnaAtomParams{0.061, 1.75, g.charge};  // AMBER "F" (src/pydock.rs VDW tables)
+                const DnaRecord *like = find_dna_record(g.like);
+                return DnaAtomParams{like->well_depth, like->radius, g.charge};
+            }
+        }
     }
-    if (!rec) throw Error(LD_ERR_UNSUPPORTED, "DNA Error: Atom [\"" + key + "\"] not supported");
+    if (!rec) throw Error(LD_ERR_UNSUPPORTED, who + " Error: Atom [\"" + key + "\"] not supported");
     if (std::isnan(rec->charge))
-        throw Error(LD_ERR_UNSUPPORTED, "DNA Error: Atom [\"" + key + "\"] electrostatics charge not found");
+        throw Error(LD_ERR_UNSUPPORTED, who + " Error: Atom [\"" + key + "\"] electrostatics charge not found");
     if (std::isnan(rec->well_depth))
-        throw Error(LD_ERR_UNSUPPORTED, "DNA Error: Atom [\"" + key + "\"] VDW charge not found");
+        throw Error(LD_ERR_UNSUPPORTED, who + " Error: Atom [\"" + key + "\"] VDW charge not found");
     if (std::isnan(rec->radius))
-        throw Error(LD_ERR_UNSUPPORTED, "DNA Error: Atom [\"" + key + "\"] VDW radius not found");
+        throw Error(LD_ERR_UNSUPPORTED, who + " Error: Atom [\"" + key + "\"] VDW radius not found");
     return DnaAtomParams{rec->well_depth, rec->radius, rec->charge};
 }
 
@@ -141,8 +158,8 @@ DockingModel build_docking_model(int method, const Structure &structure,
 
         if (method == LD_METHOD_DFIRE) {
             m.dfire_types.push_back(dfire_atom_type(a.res_name, a.name));
-        } else if (method == LD_METHOD_DNA) {
-            DnaAtomParams p = dna_atom_params(a.res_name, a.name);
+        } else if (method == LD_METHOD_DNA || method == LD_METHOD_PYDOCK) {
+            DnaAtomParams p = dna_atom_params(a.res_name, a.name, method == LD_METHOD_PYDOCK);
             m.ele_charges.push_back(p.charge);
             m.vdw_charges.push_back(p.well_depth);
             m.vdw_radii.push_back(p.radius);

@@ -36,7 +36,9 @@ uint32_t dfire_atom_type(const std::string &res_name, const std::string &atom_na
 
 struct DnaAtomParams { double well_depth, radius, charge; };
 // DNA parameters of (residue, atom) incl. the H1/H2/H3 -> "<res>-H" rule (src/dna.rs:314-358).
-DnaAtomParams dna_atom_params(const std::string &res_name, const std::string &atom_name);
+// generic_fallback = PYDOCK: an atom the tables do not know is typed by the first letter of its
+// name ("*-C", "*-F", "*-H", "*-N", "*-O", "*-S"; src/pydock.rs:332-345).
+DnaAtomParams dna_atom_params(const std::string &res_name, const std::string &atom_name, bool generic_fallback = false);
 
 DockingModel build_docking_model(int method, const Structure &structure,
                                  const std::vector<std::string> &active_restraints,

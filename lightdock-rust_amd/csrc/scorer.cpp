@@ -226,9 +226,10 @@ void Scorer::upload_molecule(const ld_molecule &m, bool is_receptor, DeviceMolec
 }
 
 Scorer::Scorer(const ld_scorer_desc &desc) {
-    if (desc.method != LD_METHOD_DFIRE && desc.method != LD_METHOD_DNA)
+    if (desc.method != LD_METHOD_DFIRE && desc.method != LD_METHOD_DNA && desc.method != LD_METHOD_PYDOCK)
         throw Error(LD_ERR_UNSUPPORTED, "Error: method not supported");
-    method_ = desc.method;
+    // PYDOCK's energy is DNA's (src/pydock.rs:425-545 == src/dna.rs:411-529); only the model builder differs
+    method_ = desc.method == LD_METHOD_PYDOCK ? LD_METHOD_DNA : desc.method;
     use_anm_ = desc.use_anm != 0;
     check_molecule(desc.receptor, method_, "receptor", use_anm_);
     check_molecule(desc.ligand, method_, "ligand", use_anm_);

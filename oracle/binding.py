@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libld_oracle.so")
 CLI_PATH = os.path.join(HERE, "ld_oracle_cli")
 TABLE_LEN = 169 * 169 * 20
-METHODS = {"dfire": 0, "dna": 1}
+METHODS = {"dfire": 0, "dna": 1, "pydock": 2}
 
 _lib = None
 

@@ -444,6 +444,12 @@ static const char *kv_str_find(const orc_kv_str *t, int n, const char *key) {
     return NULL;
 }
 
+/* the six generic entries PYDOCK adds to the AMBER type / charge tables (src/pydock.rs AMBER_TYPES,
+ * ELE_CHARGES: "*-C", "*-F", "*-H", "*-N", "*-O", "*-S") */
+static const struct { char element; const char *amber; double charge; } PYDOCK_GENERIC[] = {
+    {'C', "C", 0.5973}, {'F', "F", -0.342}, {'H', "H", 0.2719}, {'N', "N", -0.4157}, {'O', "O", -0.5679}, {'S', "S", -0.2737},
+};
+
 static int str_in_list(const char *s, const char *const *list, int n) {
     for (int i = 0; i < n; i++)
         if (list[i] && strcmp(s, list[i]) == 0) return 1;
@@ -465,7 +471,7 @@ static int model_build(model_t *m, int method, const char *pdb_path, const char 
     m->restraint_ids = (char(*)[32])calloc(n ? n : 1, 32);
     uint32_t *atom_group = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t)); /* group id or ~0 */
     char(*passive_ids)[32] = (char(*)[32])calloc(n ? n : 1, 32);
-    if (method == ORC_METHOD_DNA) {
+    if (method != ORC_METHOD_DFIRE) {
         m->vdw_radii = (double *)calloc(n ? n : 1, sizeof(double));
         m->vdw_charges = (double *)calloc(n ? n : 1, sizeof(double));
         m->ele_charges = (double *)calloc(n ? n : 1, sizeof(double));
@@ -509,24 +515,31 @@ static int model_build(model_t *m, int method, const char *pdb_path, const char 
         } else { /* dna.rs:314-358 */
             char atom_id[24];
             snprintf(atom_id, sizeof atom_id, "%s-%s", a->resname, a->name);
+            const char *who = method == ORC_METHOD_PYDOCK ? "PYDOCK" : "DNA";
             const char *amber = kv_str_find(ORC_AMBER_TYPES, ORC_AMBER_TYPES_LEN, atom_id);
+            double charge, eps, radius;
+            int have_charge = 0;
             if (!amber) {
                 if (!strcmp(a->name, "H1") || !strcmp(a->name, "H2") || !strcmp(a->name, "H3")) {
                     snprintf(atom_id, sizeof atom_id, "%s-H", a->resname);
                     amber = kv_str_find(ORC_AMBER_TYPES, ORC_AMBER_TYPES_LEN, atom_id);
+                } else if (method == ORC_METHOD_PYDOCK) { /* pydock.rs:332-345: "*-<first letter>" */
+                    if (a->name[0] == 0) { set_err("PYDOCK Error: Atom element could not be guessed from [\"%s\"]", a->name); rc = -1; break; }
+                    snprintf(atom_id, sizeof atom_id, "*-%c", a->name[0]);
+                    for (size_t g = 0; g < sizeof PYDOCK_GENERIC / sizeof PYDOCK_GENERIC[0]; g++)
+                        if (PYDOCK_GENERIC[g].element == a->name[0]) { amber = PYDOCK_GENERIC[g].amber; charge = PYDOCK_GENERIC[g].charge; have_charge = 1; }
                 }
-                if (!amber) { set_err("DNA Error: Atom [\"%s\"] not supported", atom_id); rc = -1; break; }
+                if (!amber) { set_err("%s Error: Atom [\"%s\"] not supported", who, atom_id); rc = -1; break; }
             }
-            double charge, eps, radius;
-            if (!kv_num_find(ORC_ELE_CHARGES, ORC_ELE_CHARGES_LEN, atom_id, &charge) &&
+            if (!have_charge && !kv_num_find(ORC_ELE_CHARGES, ORC_ELE_CHARGES_LEN, atom_id, &charge) &&
                 !kv_num_find(ORC_NT_ELE_CHARGES, ORC_NT_ELE_CHARGES_LEN, atom_id, &charge)) {
-                set_err("DNA Error: Atom [\"%s\"] electrostatics charge not found", atom_id); rc = -1; break;
+                set_err("%s Error: Atom [\"%s\"] electrostatics charge not found", who, atom_id); rc = -1; break;
             }
             if (!kv_num_find(ORC_VDW_CHARGES, ORC_VDW_CHARGES_LEN, amber, &eps)) {
-                set_err("DNA Error: Atom [\"%s\"] VDW charge not found", atom_id); rc = -1; break;
+                set_err("%s Error: Atom [\"%s\"] VDW charge not found", who, atom_id); rc = -1; break;
             }
             if (!kv_num_find(ORC_VDW_RADII, ORC_VDW_RADII_LEN, amber, &radius)) {
-                set_err("DNA Error: Atom [\"%s\"] VDW radius not found", atom_id); rc = -1; break;
+                set_err("%s Error: Atom [\"%s\"] VDW radius not found", who, atom_id); rc = -1; break;
             }
             m->ele_charges[i] = charge;
             m->vdw_charges[i] = eps;
@@ -583,7 +596,7 @@ orc_scorer *orc_scorer_new(int method, const char *receptor_pdb, const char *lig
                            const char *const *lig_active, int n_lig_active, const char *const *lig_passive,
                            int n_lig_passive, const double *lig_nmodes, size_t lig_nmodes_len, int lig_num_anm,
                            int use_anm, const double *potential) {
-    if (method != ORC_METHOD_DFIRE && method != ORC_METHOD_DNA) { set_err("Error: method not supported"); return NULL; }
+    if (method != ORC_METHOD_DFIRE && method != ORC_METHOD_DNA && method != ORC_METHOD_PYDOCK) { set_err("Error: method not supported"); return NULL; }
     orc_scorer *s = (orc_scorer *)calloc(1, sizeof *s);
     s->method = method;
     s->use_anm = use_anm;

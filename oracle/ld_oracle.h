@@ -31,6 +31,7 @@ extern "C" {
 
 #define ORC_METHOD_DFIRE 0
 #define ORC_METHOD_DNA 1
+#define ORC_METHOD_PYDOCK 2 /* src/pydock.rs: DNA's energy + a generic-element fallback for unknown atoms */
 #define ORC_DFIRE_TABLE_LEN (169 * 169 * 20) /* src/dfire.rs:216,251 */
 
 const char *orc_last_error(void);

@@ -283,7 +283,8 @@ int orc_cli_main(int argc, char **argv) {
     const char *method_dbg;
     if (!strcmp(method_type, "dfire")) { method = ORC_METHOD_DFIRE; method_dbg = "DFIRE"; }
     else if (!strcmp(method_type, "dna")) { method = ORC_METHOD_DNA; method_dbg = "DNA"; }
-    else { fprintf(stderr, "Error: method not supported\n"); return 0; } /* bin:105-115 (pydock: out of scope) */
+    else if (!strcmp(method_type, "pydock")) { method = ORC_METHOD_PYDOCK; method_dbg = "PYDOCK"; }
+    else { fprintf(stderr, "Error: method not supported\n"); return 0; } /* bin:105-115 */
 
     setup_t setup;
     char err[512], dbg[1200];

@@ -460,3 +460,58 @@ def test_cli_100_steps_matches_reference_files_1azp(pkg, tmp_path):
         assert np.max(np.abs(got[3] - want[3])) <= 1.01e-3
         assert np.all(np.abs(got[1] - want[1]) <= 1.01e-8 + 1e-9 * np.abs(want[1]))
         assert np.all(np.abs(got[4] - want[4]) <= 1.01e-8 + 1e-9 * np.abs(want[4]))
+
+
+def test_pydock_method(pkg, orc, scorers, tmp_path):
+    """Method::PYDOCK (src/scoring.rs:5-9): DNA's energy behind the pydock model builder."""
+    d = os.path.join(GOLDEN, "unit", "1azp")
+    rec, lig = os.path.join(d, "1azp_receptor.pdb"), os.path.join(d, "1azp_ligand.pdb")
+    s = pkg.Scorer.from_pdb("pydock", rec, lig)
+    assert abs(s.energy([0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]) - (-364.88126358158974)) < 1e-10 * 364.9   # src/pydock.rs:586
+    odd = tmp_path / "odd.pdb"
+    odd.write_text("ATOM      1  CQ1 LIG A   1       1.104   3.207   2.100  1.00  0.00           C\n"
+                   "ATOM      2  F7  LIG A   1       2.104   3.207   2.100  1.00  0.00           F\n"
+                   "ATOM      3  S1  LIG A   1       2.104   4.207   2.100  1.00  0.00           S\n")
+    hip, cpu = pkg.Scorer.from_pdb("pydock", str(odd), lig), orc.Scorer("pydock", str(odd), lig)
+    poses = np.array([[0, 0, 0, 1, 0, 0, 0], [3.0, -2.0, 1.0, 0.5, 0.5, -0.5, 0.5]], dtype=np.float64)
+    assert rel_err(hip.energy_batch(poses), cpu.energy_rows(poses)) < REL_TOL
+    # the CLI accepts the third method name
+    src = os.path.join(GOLDEN, "1azp")
+    for f in ("rec_nm.npy", "lig_nm.npy"):
+        shutil.copy(os.path.join(src, f), tmp_path)
+    r = subprocess.run([pkg.CLI_PATH, os.path.join(src, "setup.json"), os.path.join(src, "initial_positions_0.dat"),
+                        "1", "PyDock"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0 and "Loading PYDOCK scoring function" in r.stdout
+    got = parse_gso(os.path.join(tmp_path, "swarm_0", "gso_1.out"))
+    want = parse_gso(os.path.join(src, "swarm_0", "gso_1.out"))          # identical to the DNA run
+    assert np.all(np.abs(got[4] - want[4]) <= 1.01e-8 + 1e-9 * np.abs(want[4]))
+
+
+def test_multi_swarm_launcher(pkg, tmp_path):
+    """launch.py (the ant_thony.py replacement): three swarms in one batched GSO write the same
+    files as three runs of the single-swarm CLI."""
+    src = os.path.join(GOLDEN, "1azp")
+    run, init = tmp_path / "run", tmp_path / "init"
+    run.mkdir(), init.mkdir()
+    for f in ("rec_nm.npy", "lig_nm.npy"):
+        shutil.copy(os.path.join(src, f), run)
+    base = open(os.path.join(src, "initial_positions_0.dat")).read().splitlines()
+    for s, shift in ((0, 0), (1, 60), (2, 120)):
+        (init / ("initial_positions_%d.dat" % s)).write_text("\n".join(base[shift:shift + 64]) + "\n")
+    launcher = os.path.join(os.path.dirname(pkg.__file__), "launch.py")
+    r = subprocess.run([os.sys.executable, launcher, os.path.join(src, "setup.json"), "12", "dna", "--swarms", "0-2",
+                        "--init-dir", str(init)], cwd=run, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for s in range(3):
+        single = tmp_path / ("single%d" % s)
+        single.mkdir()
+        for f in ("rec_nm.npy", "lig_nm.npy"):
+            shutil.copy(os.path.join(src, f), single)
+        r = subprocess.run([pkg.CLI_PATH, os.path.join(src, "setup.json"), str(init / ("initial_positions_%d.dat" % s)),
+                            "12", "dna"], cwd=single, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for step in (1, 10):
+            a = open(run / ("swarm_%d" % s) / ("gso_%d.out" % step)).read()
+            b = open(single / ("swarm_%d" % s) / ("gso_%d.out" % step)).read()
+            assert a == b
+        assert not os.path.exists(run / ("swarm_%d" % s) / "gso_12.out")

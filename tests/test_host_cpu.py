@@ -199,3 +199,29 @@ def test_product_has_no_cpu_fallback(pkg, table):
                 src.append(open(os.path.join(dirpath, f), errors="ignore").read())
     blob = "\n".join(src)
     assert "ld_oracle" not in blob and "oracle/" not in blob.replace("no oracle/_ref", "")
+
+
+def test_pydock_host_builder_matches_oracle(pkg, orc, tmp_path):
+    odd = tmp_path / "odd.pdb"
+    odd.write_text("ATOM      1  CQ1 LIG A   1      11.104  13.207   2.100  1.00  0.00           C\n"
+                   "ATOM      2  F7  LIG A   1      12.104  13.207   2.100  1.00  0.00           F\n"
+                   "ATOM      3  S1  LIG A   1      12.104  14.207   2.100  1.00  0.00           S\n"
+                   "ATOM      4  N2  LIG A   1      12.104  14.207   3.100  1.00  0.00           N\n"
+                   "ATOM      5  O9  LIG A   1      12.104  15.207   3.100  1.00  0.00           O\n"
+                   "ATOM      6  H77 LIG A   1      12.104  15.207   4.100  1.00  0.00           H\n"
+                   "ATOM      7  CA  ALA A   2      13.104  15.207   4.100  1.00  0.00           C\n")
+    lig = os.path.join(GOLDEN, "unit", "1azp", "1azp_ligand.pdb")
+    w = orc.Scorer("pydock", str(odd), lig).model(0)
+    m = pkg.model_from_pdb("pydock", str(odd))
+    for k in ("ele_charges", "vdw_charges", "vdw_radii"):
+        assert np.array_equal(m[k], w[k]), k
+    with pytest.raises(pkg.LightdockError, match=r'DNA Error: Atom \["LIG-CQ1"\] not supported'):
+        pkg.model_from_pdb("dna", str(odd))
+    odd.write_text("ATOM      1  XX  LIG A   1      11.104  13.207   2.100  1.00  0.00           X\n")
+    with pytest.raises(pkg.LightdockError, match=r'PYDOCK Error: Atom \["\*-X"\] not supported'):
+        pkg.model_from_pdb("pydock", str(odd))
+    # every atom of the real fixtures types identically under dna and pydock
+    for f in ("1azp_receptor.pdb", "1azp_ligand.pdb"):
+        p = os.path.join(GOLDEN, "unit", "1azp", f)
+        a, b = pkg.model_from_pdb("dna", p), pkg.model_from_pdb("pydock", p)
+        assert all(np.array_equal(a[k], b[k]) for k in ("ele_charges", "vdw_charges", "vdw_radii"))

@@ -119,3 +119,28 @@ def test_real_dcparams_goldens(orc, real_dcparams):
     d = os.path.join(GOLDEN, "unit", "2oob")
     s = orc.Scorer("dfire", os.path.join(d, "2oob_receptor.pdb"), os.path.join(d, "2oob_ligand.pdb"), potential=t)
     assert s.energy([0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]) == 16.7540569503498
+
+
+def test_pydock_known_answer_and_generic_fallback(orc, tmp_path):
+    """src/pydock.rs:553-587: same golden as DNA; src/pydock.rs:332-345: unknown atoms are typed
+    by the first letter of their name, H1/H2/H3 still only fall back to "<res>-H"."""
+    d = os.path.join(GOLDEN, "unit", "1azp")
+    rec, lig = os.path.join(d, "1azp_receptor.pdb"), os.path.join(d, "1azp_ligand.pdb")
+    s = orc.Scorer("pydock", rec, lig)
+    assert s.energy([0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]) == -364.88126358158974
+    odd = tmp_path / "odd.pdb"
+    odd.write_text("ATOM      1  CQ1 LIG A   1      11.104  13.207   2.100  1.00  0.00           C\n"
+                   "ATOM      2  F7  LIG A   1      12.104  13.207   2.100  1.00  0.00           F\n"
+                   "ATOM      3  S1  LIG A   1      12.104  14.207   2.100  1.00  0.00           S\n")
+    s = orc.Scorer("pydock", str(odd), lig)
+    m = s.model(0)
+    assert list(m["ele_charges"]) == [0.5973, -0.342, -0.2737]
+    assert list(m["vdw_charges"]) == [0.086, 0.061, 0.25] and list(m["vdw_radii"]) == [1.908, 1.75, 2.0]
+    with pytest.raises(RuntimeError, match=r'DNA Error: Atom \["LIG-CQ1"\] not supported'):
+        orc.Scorer("dna", str(odd), lig)
+    odd.write_text("ATOM      1  XX  LIG A   1      11.104  13.207   2.100  1.00  0.00           X\n")
+    with pytest.raises(RuntimeError, match=r'PYDOCK Error: Atom \["\*-X"\] not supported'):
+        orc.Scorer("pydock", str(odd), lig)
+    odd.write_text("ATOM      1  H2  LIG A   1      11.104  13.207   2.100  1.00  0.00           H\n")
+    with pytest.raises(RuntimeError, match=r'PYDOCK Error: Atom \["LIG-H"\] not supported'):
+        orc.Scorer("pydock", str(odd), lig)
