@@ -28,7 +28,7 @@ struct DeviceMolecule {
     const uint32_t *tindex = nullptr;
     // tracked-atom slot (bit index into the per-pose interface flag words) or -1
     const int32_t *slot = nullptr;
-    // DNA per-atom parameters
+    // DNA per-atom parameters; well_depth holds sqrt(eps) (src/dna.rs:495 takes sqrt(eps_i*eps_j) per pair)
     const double *charge = nullptr, *well_depth = nullptr, *radius = nullptr;
     // ANM modes re-laid out as [mode][xyz][n_pad] so atom-consecutive lanes load coalesced
     int num_anm = 0;

@@ -187,7 +187,11 @@ void Scorer::upload_molecule(const ld_molecule &m, bool is_receptor, DeviceMolec
         host.vdw_charges.assign(m.vdw_charges, m.vdw_charges + n);
         host.vdw_radii.assign(m.vdw_radii, m.vdw_radii + n);
         dev.charge = arena_.upload(host.ele_charges, n_pad);
-        dev.well_depth = arena_.upload(host.vdw_charges, n_pad);
+        {   // the kernel multiplies sqrt(eps_i) * sqrt(eps_j) instead of sqrt(eps_i * eps_j) per pair
+            std::vector<double> root(host.vdw_charges);
+            for (double &v : root) v = std::sqrt(v);
+            dev.well_depth = arena_.upload(root, n_pad);
+        }
         dev.radius = arena_.upload(host.vdw_radii, n_pad);
     }
 
