@@ -139,6 +139,10 @@ def main():
     step(counts=True)
     torch.cuda.synchronize()
     p_cut = d_cnt.cpu().numpy().astype(np.int64)
+    try:
+        blocks = float(scorer.last_block_counts(args.batch).mean())     # 8x8 blocks the box culling let through
+    except pkg.LightdockError:
+        blocks = None
     algo_bytes_launch = float(info["stream_bytes_per_pose"] * args.batch + 8 * p_cut.sum())
 
     multi = pkg.multi
@@ -170,14 +174,14 @@ def main():
             "config": {"workload": "%s DFIRE pose-energy batch, %d poses/GPU/step, %d x %d atoms, synthetic DCparams"
                                    % (args.workload, args.batch, scorer.num_atoms(0), scorer.num_atoms(1)),
                        "poses_per_step_per_gpu": args.batch, "pair_tests_per_pose": info["pair_tests_per_pose"],
-                       "mean_pairs_in_cutoff": float(p_cut.mean()), "parallelism": "swarm-sharded x%d, no collectives" % world},
+                       "mean_pairs_in_cutoff": float(p_cut.mean()), "mean_8x8_blocks_evaluated": blocks, "parallelism": "swarm-sharded x%d, no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, info),
                          "kernel": info["pair_kernel_name"], "kernel_ms": 1e3 * kern_s,
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "pair_tests_per_s": info["pair_tests_per_pose"] * args.batch / kern_s},
         }
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:      # reported baseline: rank 0 at N = 1 only
             threads = min(len(os.sched_getaffinity(0)), 64)
             cb, cpu_e = cpu_baseline(case, table, poses, args.cpu_seconds, threads)
             out["cpu_baseline"] = cb

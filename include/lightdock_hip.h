@@ -161,6 +161,12 @@ int ld_scorer_energy_batch(ld_scorer *s, size_t n, const double *poses, size_t s
 int ld_scorer_energy_batch_device(ld_scorer *s, size_t n, const double *d_poses, size_t stride,
                                   const uint8_t *d_active, double *d_energies_out, uint32_t *d_pair_counts);
 
+/* Diagnostics of the box-culled DFIRE kernel: after a ld_scorer_energy_batch_device call WITH
+ * pair_counts, the number of 8x8 atom-pair blocks each of those n poses actually evaluated
+ * (64 pair tests each; compare with n_rec*n_lig/64 for all pairs).  Synchronises.  Returns
+ * LD_ERR_UNSUPPORTED for scorers that run the all-pairs kernel. */
+int ld_scorer_last_block_counts(ld_scorer *s, size_t n, uint32_t *blocks_out_host);
+
 /* Per-launch facts for the measurement harness. */
 typedef struct ld_kernel_info {
     const char *pair_kernel_name; /* symbol of the dominant (pair loop) kernel */

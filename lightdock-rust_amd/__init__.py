@@ -84,6 +84,7 @@ def load_library():
     lib.ld_scorer_energy_batch.argtypes = [vp, sz, vp, sz, vp]
     lib.ld_scorer_energy_batch_device.argtypes = [vp, sz, vp, sz, vp, vp, vp]
     lib.ld_scorer_kernel_info.argtypes = [vp, C.POINTER(_KernelInfo)]
+    lib.ld_scorer_last_block_counts.argtypes = [vp, sz, vp]
     lib.ld_scorer_enable_timing.argtypes = [vp, C.c_int]
     lib.ld_scorer_pair_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.ld_gso_create.restype = vp
@@ -332,6 +333,12 @@ class Scorer:
         ms, n = C.c_double(), C.c_uint64()
         _check(self.lib.ld_scorer_pair_kernel_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def last_block_counts(self, n):
+        """8x8 atom-pair blocks evaluated per pose in the last counting launch (tiled DFIRE kernel)."""
+        out = np.zeros(n, dtype=np.uint32)
+        _check(self.lib.ld_scorer_last_block_counts(self._h, n, _ptr(out)))
+        return out
 
     def kernel_info(self):
         info = _KernelInfo()

@@ -234,6 +234,13 @@ int ld_scorer_energy_batch_device(ld_scorer *s, size_t n, const double *d_poses,
     });
 }
 
+int ld_scorer_last_block_counts(ld_scorer *s, size_t n, uint32_t *blocks_out_host) {
+    return guarded([&] {
+        if (!s) throw ld::Error(LD_ERR_INVALID, "null scorer");
+        s->impl.last_block_counts(n, blocks_out_host);
+    });
+}
+
 int ld_scorer_kernel_info(const ld_scorer *s, ld_kernel_info *out) {
     return guarded([&] {
         if (!s || !out) throw ld::Error(LD_ERR_INVALID, "null argument");

@@ -574,6 +574,21 @@ void Scorer::energy_batch_host(size_t n, const double *poses, size_t stride, dou
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
 }
 
+void Scorer::last_block_counts(size_t n, uint32_t *out_host) {
+    if (!use_tiled_) throw Error(LD_ERR_UNSUPPORTED, "block counts exist for the tiled DFIRE kernel only");
+    if (!out_host) throw Error(LD_ERR_INVALID, "null output");
+    const size_t groups = (size_t)tiled_.n_groups;
+    if (ws_tested_.bytes < n * groups * sizeof(uint32_t)) throw Error(LD_ERR_INVALID, "no counting launch of that size has run");
+    std::vector<uint32_t> part(n * groups);
+    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    hip_check(hipMemcpy(part.data(), ws_tested_.ptr, part.size() * sizeof(uint32_t), hipMemcpyDeviceToHost), "D2H block counts");
+    for (size_t p = 0; p < n; p++) {
+        uint32_t t = 0;
+        for (size_t g = 0; g < groups; g++) t += part[p * groups + g];
+        out_host[p] = t;
+    }
+}
+
 void Scorer::enable_timing(bool on) { timing_ = on; }
 
 void Scorer::pair_kernel_time(double *total_ms, uint64_t *launches) {

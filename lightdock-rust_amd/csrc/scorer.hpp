@@ -91,7 +91,7 @@ class Scorer {
 
     void kernel_info(ld_kernel_info *out) const;
     // diagnostics of the last counting launch: 8x8 atom-pair blocks evaluated per pose (tiled kernel)
-    const uint32_t *tested_blocks_device() const { return static_cast<const uint32_t *>(ws_tested_.ptr); }
+    void last_block_counts(size_t n, uint32_t *out_host);
     void enable_timing(bool on);
     void pair_kernel_time(double *total_ms, uint64_t *launches);
 

@@ -515,3 +515,24 @@ def test_multi_swarm_launcher(pkg, tmp_path):
             b = open(single / ("swarm_%d" % s) / ("gso_%d.out" % step)).read()
             assert a == b
         assert not os.path.exists(run / ("swarm_%d" % s) / "gso_12.out")
+
+
+def test_block_count_diagnostics(pkg, scorers, orc):
+    """The culled kernel evaluates far fewer 8x8 blocks than all pairs, never fewer than the
+    in-cutoff pairs need."""
+    torch = pytest.importorskip("torch")
+    hip, cpu = scorers("1k4c")
+    poses = case_positions("1k4c", orc)[:32]
+    dev = torch.device("cuda:0")
+    d_poses = torch.from_numpy(poses).to(dev)
+    d_out = torch.zeros(32, dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(32, dtype=torch.int32, device=dev)
+    hip.energy_batch_device(32, d_poses.data_ptr(), 7, d_out.data_ptr(), None, d_cnt.data_ptr())
+    blocks = hip.last_block_counts(32).astype(np.int64)
+    hits = d_cnt.cpu().numpy().astype(np.int64)
+    all_blocks = 3413 * 3268 / 64.0
+    assert np.all(blocks * 64 >= hits)
+    assert blocks.mean() < 0.08 * all_blocks          # ~3.7 % of the pair blocks survive the box tests
+    dna, _ = scorers("1azp")
+    with pytest.raises(pkg.LightdockError, match="tiled DFIRE kernel only"):
+        dna.last_block_counts(4)
