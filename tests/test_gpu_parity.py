@@ -536,3 +536,32 @@ def test_block_count_diagnostics(pkg, scorers, orc):
     dna, _ = scorers("1azp")
     with pytest.raises(pkg.LightdockError, match="tiled DFIRE kernel only"):
         dna.last_block_counts(4)
+
+
+def test_gso_config5_per_gpu_share(pkg, scorers, orc):
+    """BASELINE config 5 as one GPU sees it (1024 swarms over 8 GPUs = 128 swarms x 200
+    glowworms, 1ppe DFIRE): size-independent properties at full size -- replicated swarms stay
+    bit-identical wherever they sit in the batch, sampled swarms equal the oracle, the
+    evaluation count is the number of moved glowworms."""
+    hip, cpu = scorers("1ppe")
+    base = case_positions("1ppe", orc)
+    n_swarms, steps = 128, 8
+    swarms = [base] + [pkg.synth.swarm(200, seed=k) for k in range(1, n_swarms)]
+    swarms[77] = swarms[3]                     # two replicated pairs
+    swarms[127] = swarms[0]
+    gso = pkg.GSO(hip, np.stack(swarms))
+    gso.run(steps)
+    a, b = gso.read(3), gso.read(77)
+    c, d = gso.read(0), gso.read(127)
+    for k in ("poses", "luciferin", "scoring", "n_neighbors", "target"):
+        assert np.array_equal(a[k], b[k]) and np.array_equal(c[k], d[k]), k
+    total = 0
+    for s in (0, 3, 64):
+        ref = orc.GSO(cpu, swarms[s])
+        for _ in range(steps):
+            ref.step()
+        st, want = gso.read(s), ref.state()
+        assert np.array_equal(st["n_neighbors"], want["n_neighbors"]) and np.array_equal(st["target"], want["target"])
+        assert rel_err(st["scoring"], want["scoring"]) < REL_TOL
+        total += ref.num_evals
+    assert gso.num_evals >= total and gso.steps_done == steps
