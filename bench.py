@@ -48,15 +48,30 @@ def read_positions(path):
     return np.array([[float(v) for v in line.split(" ")] for line in open(path).read().splitlines()])[:, :7]
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(case, table, poses, budget_s, threads):
-    """Time the CPU oracle (test infrastructure used ONLY as the reported baseline) on `threads`
-    host threads over as many of the bench poses as fit the budget."""
+    """Time the CPU oracle (test infrastructure used ONLY as the reported baseline) over a bounded
+    sample of the bench poses: (a) one thread, the stand-in for the single-threaded Rust path;
+    (b) `threads` host threads, one pose stream each, the stand-in for `ant_thony.py --cores N`."""
     orc = ge.oracle()
     scorer = orc.Scorer(case["method"], case["rec"], case["lig"], potential=table, **case["kw"])
+    scorer.energy_row(poses[0])                                   # warm
+    n1 = 0
     t0 = time.perf_counter()
-    scorer.energy_row(poses[0])
-    per_eval = max(time.perf_counter() - t0, 1e-6)
-    n = int(max(threads, min(len(poses), budget_s / per_eval)))
+    while time.perf_counter() - t0 < min(2.0, budget_s / 8) and n1 < len(poses):
+        scorer.energy_row(poses[n1])
+        n1 += 1
+    single = n1 / (time.perf_counter() - t0)
+    n = int(max(threads, min(len(poses), (budget_s * 7 / 8) * single)))
     n -= n % threads
     sample = poses[:n]
     out = np.zeros(n)
@@ -72,8 +87,10 @@ def cpu_baseline(case, table, poses, budget_s, threads):
     for t in ths:
         t.join()
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "evals/s", "cores": threads, "kind": "port",
-            "sample": "%d of the bench poses, %d threads, %.1f s wall (C oracle -O2, f64, no SIMD intrinsics)" % (n, threads, dt)}, out
+    return {"value": n / dt, "unit": "evals/s", "cores": threads, "kind": "port", "single_thread_value": single,
+            "cpu_model": cpu_model(),
+            "sample": "%d of the bench poses on %d threads in %.1f s wall (+ %d poses on 1 thread); C oracle -O2, f64, "
+                      "no SIMD intrinsics" % (n, threads, dt, n1)}, out
 
 
 def measured_traffic(args, info):
