@@ -1,5 +1,6 @@
 #include "gso.hpp"
 
+#include <algorithm>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -21,7 +22,8 @@ Gso::Gso(Scorer &scorer, size_t n_swarms, size_t n_glowworms, const double *posi
     poses_[0] = arena_.upload(rows);
     poses_[1] = arena_.upload(rows);
     // Glowworm::new defaults, src/glowworm.rs:45-57
-    luciferin_ = arena_.upload(std::vector<double>(total, 5.0));
+    luciferin_[0] = arena_.upload(std::vector<double>(total, 5.0));
+    luciferin_[1] = arena_.upload(std::vector<double>(total, 5.0));
     vision_ = arena_.upload(std::vector<double>(total, 0.2));
     scoring_ = arena_.upload(std::vector<double>(total, 0.0));
     active_ = arena_.upload(std::vector<uint8_t>(total, 1));  // step == 0: everybody is scored
@@ -29,7 +31,9 @@ Gso::Gso(Scorer &scorer, size_t n_swarms, size_t n_glowworms, const double *posi
     std::vector<int32_t> self(total);
     for (size_t i = 0; i < total; i++) self[i] = (int32_t)(i % n_glowworms);
     target_ = arena_.upload(self);
-    step_ = arena_.upload(std::vector<uint32_t>(n_swarms, 0));
+    step_ = arena_.upload(std::vector<uint32_t>(total, 0));
+    // K2 workgroups per swarm: aim at >= 512 workgroups, at least 64 glowworms each
+    parts_ = (int)std::min<size_t>((n_glowworms + 63) / 64, std::max<size_t>(1, (512 + n_swarms - 1) / n_swarms));
     std::vector<uint32_t> keys(8 * n_swarms);
     for (size_t s = 0; s < n_swarms; s++) stdrng_key_from_seed(seeds ? seeds[s] : 324324ULL, &keys[8 * s]);  // src/lib.rs:38
     rng_key_ = arena_.upload(keys);
@@ -52,7 +56,9 @@ void Gso::step() {
     g.anm_lig = (int)scorer_.anm_lig();
     g.poses_in = poses_[cur_];
     g.poses_out = poses_[cur_ ^ 1];
-    g.luciferin = luciferin_;
+    g.luciferin_in = luciferin_[cur_];
+    g.luciferin_out = luciferin_[cur_ ^ 1];
+    g.parts = parts_;
     g.vision = vision_;
     g.scoring = scoring_;
     g.active = active_;
@@ -135,7 +141,7 @@ void Gso::read(size_t swarm, double *poses, double *luciferin, double *vision, d
         if (dst) hip_check(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost), "D2H state");
     };
     pull(poses, poses_[cur_] + off * pose_len_, n * pose_len_ * sizeof(double));
-    pull(luciferin, luciferin_ + off, n * sizeof(double));
+    pull(luciferin, luciferin_[cur_] + off, n * sizeof(double));
     pull(vision, vision_ + off, n * sizeof(double));
     pull(scoring, scoring_ + off, n * sizeof(double));
     pull(n_neighbors, n_neighbors_ + off, n * sizeof(int32_t));

@@ -38,7 +38,9 @@ class Gso {
     DeviceArena arena_;
     double *poses_[2] = {nullptr, nullptr};
     int cur_ = 0;
-    double *luciferin_ = nullptr, *vision_ = nullptr, *scoring_ = nullptr;
+    double *luciferin_[2] = {nullptr, nullptr};  // ping-pong with the poses
+    double *vision_ = nullptr, *scoring_ = nullptr;
+    int parts_ = 1;  // K2 workgroups per swarm
     uint8_t *active_ = nullptr;
     int32_t *n_neighbors_ = nullptr, *target_ = nullptr;
     uint32_t *step_ = nullptr, *rng_key_ = nullptr;

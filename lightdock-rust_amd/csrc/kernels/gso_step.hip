@@ -1,7 +1,8 @@
 // gso_step.hip -- K2: one GSO movement phase for every swarm of a batch (gfx950).
 //
-// Workgroup = one swarm, thread = one glowworm (grid-strided when a swarm has more
-// glowworms than threads).  Per swarm:
+// Workgroup = (swarm, share of its glowworms), thread = one glowworm (strided when a share has
+// more glowworms than threads).  Few swarms are split over several workgroups so the chip is
+// not left to one workgroup per swarm.  Per swarm:
 //   1. luciferin update, src/glowworm.rs:70 (the energies were written by K1);
 //   2. translations + luciferins of the whole swarm staged in LDS (the snapshot of
 //      src/swarm.rs:74-83 for the O(N^2) neighbour search; rotations / ANM extents of the
@@ -12,7 +13,8 @@
 //      number step*N + i is computed directly from the swarm's key;
 //   5. roulette selection (src/glowworm.rs:114-126), move (src/glowworm.rs:128-190),
 //      vision range (src/glowworm.rs:91-96).
-// Poses are double buffered (poses_in -> poses_out) so every move sees pre-move neighbours.
+// Poses and luciferins are double buffered (in -> out), so every move sees pre-move neighbours
+// and the workgroups of one swarm are independent.
 // Compiled with -ffp-contract=off: same f64 operation order as the reference.
 #include "gso_step.hpp"
 
@@ -118,14 +120,20 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int N = G.n_glowworms;
     double *sx = sh, *sy = sh + N, *sz = sh + 2 * N, *sl = sh + 3 * N;
-    const int swarm = blockIdx.x;
+    const int swarm = blockIdx.x / G.parts;
+    const int part = blockIdx.x % G.parts;
     const size_t base = (size_t)swarm * N;
-    const uint32_t done = G.step[swarm];
     const uint32_t *key = G.rng_key + 8 * swarm;
+    // this workgroup's share of the swarm
+    const int share = (N + G.parts - 1) / G.parts;
+    const int i_begin = part * share;
+    const int i_end = min(N, i_begin + share);
 
+    // every workgroup of the swarm needs all N luciferins and translations (the snapshot of
+    // src/swarm.rs:74-83); inputs are read-only this step (double buffered), so the workgroups
+    // of a swarm do not depend on each other
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
-        const double luc = (1.0 - kRho) * G.luciferin[base + i] + kGamma * G.scoring[base + i];  // glowworm.rs:70
-        G.luciferin[base + i] = luc;
+        const double luc = (1.0 - kRho) * G.luciferin_in[base + i] + kGamma * G.scoring[base + i];  // glowworm.rs:70
         sl[i] = luc;
         const double *row = G.poses_in + (base + i) * G.pose_len;
         sx[i] = row[0];
@@ -134,9 +142,11 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
     }
     __syncthreads();
 
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    for (int i = i_begin + threadIdx.x; i < i_end; i += blockDim.x) {
         const double x1 = sx[i], y1 = sy[i], z1 = sz[i], li = sl[i];
+        G.luciferin_out[base + i] = li;
         const double vr = G.vision[base + i];
+        const uint32_t done = G.step[base + i];
         // neighbours: luciferin strictly greater, distance strictly inside the vision range
         double total = 0.0;
         int cnt = 0;
@@ -201,10 +211,9 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
         G.active[base + i] = moved ? 1 : 0;
         G.n_neighbors[base + i] = cnt;
         G.target[base + i] = chosen;
+        G.step[base + i] = done + 1;  // glowworm.rs:71
         if (moved) atomicAdd(G.evals, 1ULL);  // integer: order independent
     }
-    __syncthreads();
-    if (threadIdx.x == 0) G.step[swarm] = done + 1;
 }
 
 }  // namespace
@@ -213,11 +222,12 @@ size_t gso_kernel_lds_bytes(const GsoLaunch &g) { return (size_t)4 * g.n_glowwor
 
 hipError_t launch_gso_step(const GsoLaunch &g, hipStream_t stream) {
     if (g.n_swarms == 0) return hipSuccess;
-    int threads = (g.n_glowworms + 63) / 64 * 64;
+    const int share = (g.n_glowworms + g.parts - 1) / g.parts;
+    int threads = (share + 63) / 64 * 64;
     if (threads > 1024) threads = 1024;
     if (threads < 64) threads = 64;
-    hipLaunchKernelGGL(gso_movement_phase, dim3((unsigned)g.n_swarms), dim3((unsigned)threads), gso_kernel_lds_bytes(g),
-                       stream, g);
+    hipLaunchKernelGGL(gso_movement_phase, dim3((unsigned)(g.n_swarms * g.parts)), dim3((unsigned)threads),
+                       gso_kernel_lds_bytes(g), stream, g);
     return hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
 // gso_step.hpp -- launch interface of K2, the batched GSO movement kernel.
 //
-// One workgroup per swarm, one thread per glowworm.  Covers, for every swarm at once, the
+// `parts` workgroups per swarm (each stages the whole swarm's snapshot, moves its own share of
+// the glowworms), one thread per glowworm.  Covers, for every swarm at once, the
 // second half of Glowworm::compute_luciferin (src/glowworm.rs:70-71) and the whole of
 // Swarm::movement_phase (src/swarm.rs:72-126).
 #pragma once
@@ -20,13 +21,15 @@ struct GsoLaunch {
     // state, indexed [swarm * n_glowworms + glowworm]
     const double *poses_in = nullptr;  // pre-move snapshot (rows of pose_len)
     double *poses_out = nullptr;       // post-move poses
-    double *luciferin = nullptr;
+    const double *luciferin_in = nullptr;  // luciferin before this step (double buffered like the poses)
+    double *luciferin_out = nullptr;
     double *vision = nullptr;
     const double *scoring = nullptr;
     uint8_t *active = nullptr;        // out: moved flag == "re-score next step" (src/glowworm.rs:62)
     int32_t *n_neighbors = nullptr;
     int32_t *target = nullptr;
-    uint32_t *step = nullptr;         // per swarm: completed steps; advanced by the kernel
+    uint32_t *step = nullptr;         // per glowworm: completed steps (Glowworm.step, src/glowworm.rs:71); advanced by the kernel
+    int parts = 1;                    // workgroups per swarm; each moves a contiguous share of the glowworms
     const uint32_t *rng_key = nullptr;  // per swarm: 8 ChaCha key words (rand 0.7.3 StdRng)
     unsigned long long *evals = nullptr;  // running count of energy evaluations (adds #moved)
 };
