@@ -28,7 +28,6 @@
 #include "dfire_tiled.hpp"
 
 #include <cmath>
-#include <cstdlib>
 
 namespace ld {
 
@@ -401,7 +400,6 @@ size_t tiled_kernel_lds_bytes(const TiledLaunch &t) {
     size_t b = ((kDfireLutCells + 15) & ~15) + kDfireSteps * sizeof(double);
     b += kTiledMaxWaves * sizeof(double) + kTiledMaxWaves * 2 * sizeof(uint32_t);
     b += (size_t)t.waves * 128 * sizeof(TiledAtom);
-    if (const char *e = getenv("LIGHTDOCK_TILED_LDS_PAD")) b += (size_t)atoi(e);  // occupancy experiments
     return b;
 }
 

@@ -28,6 +28,7 @@ constexpr double kNmodesStep = 0.5;       // src/constants.rs:24
 constexpr double kLinearThreshold = 0.9995;  // src/constants.rs:11
 constexpr double kRho = 0.5, kGamma = 0.4, kBeta = 0.08, kMaxVision = 5.0;  // src/glowworm.rs:45-51
 constexpr int kMaxNeighbors = 5;
+constexpr double kFarD2 = 25.5;  // > kMaxVision^2: the vision range never exceeds 5 (src/glowworm.rs:91-96)
 constexpr int kMaxAnm = 64;
 
 __device__ __forceinline__ uint32_t rotl(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
@@ -155,7 +156,9 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
             const double lj = sl[j];
             if (li < lj) {
                 const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
-                const double d = sqrt((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+                const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
+                if (d2 > kFarD2) continue;  // sqrt(d2) > 5 >= vision range: cannot be a neighbour (exact: sqrt is monotone)
+                const double d = sqrt(d2);
                 if (d < vr) {
                     total += lj - li;
                     cnt++;
@@ -174,7 +177,9 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
                 const double lj = sl[j];
                 if (!(li < lj)) continue;
                 const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
-                const double d = sqrt((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+                const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
+                if (d2 > kFarD2) continue;
+                const double d = sqrt(d2);
                 if (!(d < vr)) continue;
                 // k == 0 with rnd == 0.0, or running out of neighbours, is a panic in the
                 // reference (index under/overflow, probability ~2^-53); we keep the edge neighbour.
