@@ -565,3 +565,45 @@ def test_gso_config5_per_gpu_share(pkg, scorers, orc):
         assert rel_err(st["scoring"], want["scoring"]) < REL_TOL
         total += ref.num_evals
     assert gso.num_evals >= total and gso.steps_done == steps
+
+
+def _random_protein_pdb(path, n_atoms, seed, box):
+    """A fake but DFIRE-typable molecule: residues cycled from a template list, atoms placed at
+    random inside a box (density is irrelevant for parity)."""
+    templ = [("ALA", ["N", "CA", "C", "O", "CB"]), ("LEU", ["N", "CA", "C", "O", "CB", "CG", "CD1", "CD2"]),
+             ("LYS", ["N", "CA", "C", "O", "CB", "CG", "CD", "CE", "NZ"]), ("GLY", ["N", "CA", "C", "O"]),
+             ("TRP", ["N", "CA", "C", "O", "CB", "CG", "CD1", "CD2", "NE1", "CE2", "CE3", "CZ2", "CZ3", "CH2"]),
+             ("SER", ["N", "CA", "C", "O", "CB", "OG"]), ("ASP", ["N", "CA", "C", "O", "CB", "CG", "OD1", "OD2"])]
+    rng = np.random.default_rng(seed)
+    atoms, res = [], 0
+    while len(atoms) < n_atoms:
+        name, names = templ[res % len(templ)]
+        centre = rng.uniform(-box, box, size=3)
+        for a in names:
+            if len(atoms) == n_atoms:
+                break
+            p = centre + rng.normal(0, 1.5, size=3)
+            atoms.append((a, name, "A", res % 9000 + 1, p[0], p[1], p[2]))
+        res += 1
+    _write_pdb(path, atoms)
+
+
+def test_receptor_larger_than_one_ballot(pkg, orc, table, tmp_path):
+    """More than 64 receptor tiles (> 4096 atoms: the tile-box ballot loops) and a ligand that is
+    not a multiple of 64, against the oracle and the all-pairs kernel."""
+    rec, lig = str(tmp_path / "big_rec.pdb"), str(tmp_path / "big_lig.pdb")
+    _random_protein_pdb(rec, 4700, 1, 30.0)
+    _random_protein_pdb(lig, 333, 2, 8.0)
+    cpu = orc.Scorer("dfire", rec, lig, rec_active=["A.LEU.2", "A.TRP.5"], lig_active=["A.ALA.1"], potential=table)
+    hip = pkg.Scorer.from_pdb("dfire", rec, lig, rec_active=["A.LEU.2", "A.TRP.5"], lig_active=["A.ALA.1"], potential=table)
+    assert hip.num_atoms(0) == 4700 and hip.num_atoms(1) == 333
+    poses = pkg.synth.swarm(24, seed=9)
+    poses[:, :3] *= 0.8
+    want = cpu.energy_rows(poses)
+    assert rel_err(hip.energy_batch(poses), want) < REL_TOL
+    os.environ["LIGHTDOCK_DFIRE_KERNEL"] = "allpairs"
+    try:
+        ap = pkg.Scorer.from_pdb("dfire", rec, lig, rec_active=["A.LEU.2", "A.TRP.5"], lig_active=["A.ALA.1"], potential=table)
+    finally:
+        os.environ.pop("LIGHTDOCK_DFIRE_KERNEL")
+    assert rel_err(ap.energy_batch(poses), want) < REL_TOL
