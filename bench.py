@@ -115,12 +115,15 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="poses per GPU per step")
     ap.add_argument("--workload", default="1k4c")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU-baseline budget in core-seconds (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     args = ap.parse_args()
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("LD_BENCH_FORCE_DEVICE") is not None:      # dry runs of the N > 1 path on a 1-GPU box
+        local = int(os.environ["LD_BENCH_FORCE_DEVICE"])
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -129,7 +132,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     pkg = ge.package()
     pkg.init(local)
