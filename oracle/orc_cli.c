@@ -330,8 +330,11 @@ int orc_cli_main(int argc, char **argv) {
         snprintf(receptor_filename, sizeof receptor_filename, "%s/lightdock_%s", simulation_path, setup.receptor_pdb);
         snprintf(ligand_filename, sizeof ligand_filename, "%s/lightdock_%s", simulation_path, setup.ligand_pdb);
     }
+    /* pdbtbx::open(..).unwrap() happens here, before the ANM files are read (bin:190-214) */
     printf("Reading receptor input structure: %s\n", receptor_filename);
+    { FILE *t = fopen(receptor_filename, "r"); if (!t) { fflush(stdout); fprintf(stderr, "cannot open PDB file %s\n", receptor_filename); return 101; } fclose(t); }
     printf("Reading ligand input structure: %s\n", ligand_filename);
+    { FILE *t = fopen(ligand_filename, "r"); if (!t) { fflush(stdout); fprintf(stderr, "cannot open PDB file %s\n", ligand_filename); return 101; } fclose(t); }
 
     double *rec_nm = NULL, *lig_nm = NULL;
     size_t rec_nm_len = 0, lig_nm_len = 0;

@@ -4,6 +4,7 @@ product fails loudly (no CPU fallback) when no HIP device is present."""
 import math
 import os
 import re
+import shutil
 import subprocess
 
 import numpy as np
@@ -225,3 +226,40 @@ def test_pydock_host_builder_matches_oracle(pkg, orc, tmp_path):
         p = os.path.join(GOLDEN, "unit", "1azp", f)
         a, b = pkg.model_from_pdb("dna", p), pkg.model_from_pdb("pydock", p)
         assert all(np.array_equal(a[k], b[k]) for k in ("ele_charges", "vdw_charges", "vdw_radii"))
+
+
+def test_cli_panics_of_the_reference_exit_101(pkg, orc, tmp_path):
+    """What panics in the reference's worker thread (exit status 101 via join().unwrap(),
+    src/bin/lightdock-rust.rs:85) fails the same way in both CLIs, before any GPU work:
+    unreadable positions (bin:62), unreadable PDB (bin:201), restraints map without the
+    "active"/"passive" lists (bin:257-272), ANM file of the wrong size (bin:233)."""
+    import json as _json
+    src = os.path.join(GOLDEN, "1azp")
+    setup = _json.load(open(os.path.join(src, "setup.json")))
+    for cli in (pkg.CLI_PATH, orc.CLI_PATH):
+        run = tmp_path / os.path.basename(cli)
+        run.mkdir()
+        r = subprocess.run([cli, os.path.join(src, "setup.json"), "initial_positions_7.dat", "1", "dna"], cwd=run,
+                           capture_output=True, text=True)
+        assert r.returncode == 101 and "initial_positions_7.dat" in r.stderr
+        assert os.path.isdir(run / "swarm_7")                      # created before the positions are read, bin:176-188
+        # a setup next to which there are no lightdock_*.pdb files
+        lonely = run / "setup.json"
+        lonely.write_text(_json.dumps(setup))
+        r = subprocess.run([cli, str(lonely), os.path.join(src, "initial_positions_0.dat"), "1", "dna"], cwd=run,
+                           capture_output=True, text=True)
+        assert r.returncode == 101 and "lightdock_protein.pdb" in r.stderr
+        # restraints without "passive"
+        bad = dict(setup, receptor_restraints={"active": ["A.TRP.24"]})
+        for f in ("lightdock_protein.pdb", "lightdock_dna.pdb", "rec_nm.npy", "lig_nm.npy"):
+            shutil.copy(os.path.join(src, f), run)
+        lonely.write_text(_json.dumps(bad))
+        r = subprocess.run([cli, str(lonely), os.path.join(src, "initial_positions_0.dat"), "1", "dna"], cwd=run,
+                           capture_output=True, text=True)
+        assert r.returncode == 101 and "passive" in r.stderr
+        # ANM array that does not match the atom count
+        np.save(run / "rec_nm.npy", np.zeros(30))
+        lonely.write_text(_json.dumps(setup))
+        r = subprocess.run([cli, str(lonely), os.path.join(src, "initial_positions_0.dat"), "1", "dna"], cwd=run,
+                           capture_output=True, text=True)
+        assert r.returncode == 101 and "Number of read ANM in receptor does not correspond" in r.stderr
