@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--swarms", type=int, default=128)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--batch", type=int, default=16384)
-    ap.add_argument("--what", default="gso,dna,k1")
+    ap.add_argument("--what", default="gso,dna,k1,anm")
     args = ap.parse_args()
     import torch
     torch.cuda.init()
@@ -64,6 +64,26 @@ def main():
         s.energy_batch(poses)
         dt = time.perf_counter() - t0
         print(json.dumps({"what": "k1 1ppe dfire (host buffers, PCIe inclusive)", "poses": len(poses), "evals_per_s": len(poses) / dt}))
+    if "anm" in what:
+        d2 = os.path.join(g, "2uuy")
+        s2 = pkg.Scorer.from_pdb("dfire", os.path.join(d2, "lightdock_2UUY_rec.pdb"), os.path.join(d2, "lightdock_2UUY_lig.pdb"),
+                                 rec_nmodes=np.load(os.path.join(d2, "rec_nm.npy")), rec_num_anm=10,
+                                 lig_nmodes=np.load(os.path.join(d2, "lig_nm.npy")), lig_num_anm=10, use_anm=True, potential=table)
+        base = positions(os.path.join(d2, "initial_positions_0.dat"))
+        poses = pkg.synth.jitter(base, args.batch, seed=5)
+        dev = torch.device("cuda:0")
+        d_poses = torch.from_numpy(poses).to(dev)
+        d_out = torch.empty(args.batch, dtype=torch.float64, device=dev)
+        for _ in range(2):
+            s2.energy_batch_device(args.batch, d_poses.data_ptr(), poses.shape[1], d_out.data_ptr())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            s2.energy_batch_device(args.batch, d_poses.data_ptr(), poses.shape[1], d_out.data_ptr())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"what": "k1 2uuy dfire + receptor/ligand ANM (HBM resident, incl. per-pose receptor image)",
+                          "poses": args.batch, "evals_per_s": 5 * args.batch / dt}))
     if "dna" in what:
         d = os.path.join(g, "1azp")
         rec_nm = np.load(os.path.join(d, "rec_nm.npy"))
