@@ -122,6 +122,12 @@ void ld_model_destroy(ld_model *m);
  * lut: 901 cells of 0.25 A^2; steps[b], b = 0..20: first d2 the reference puts in bin >= b.
  * interface_d2: the largest d2 whose d = sqrt(d2)*2-1 is <= 3.9 (src/dfire.rs:339). */
 int ld_dfire_bin_lut(uint8_t *lut_out /* 901 */, double *steps_out /* 21 */, double *interface_d2_out);
+/* The atom order the tiled DFIRE kernel uses (host-side, no GPU): order_out[slot] = original atom
+ * index, UINT32_MAX for padding; length = ceil(n/64)*64.  Consecutive 8 slots ("subtile") and 64
+ * slots ("tile") are spatially compact; padding only at the tail.  The energy is a plain sum over
+ * pairs (src/dfire.rs:325-345), so the order is free.  Returns the padded length. */
+size_t ld_spatial_tile_order(const double *xyz /* n x 3 */, size_t n, uint32_t *order_out);
+
 /* rand 0.7.3 StdRng::seed_from_u64 -> the 8 ChaCha20 key words the GSO kernel uses (src/lib.rs:38). */
 void ld_stdrng_key(uint64_t seed, uint32_t key_out[8]);
 

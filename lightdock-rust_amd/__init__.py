@@ -105,6 +105,8 @@ def load_library():
     lib.ld_model_destroy.argtypes = [vp]
     lib.ld_dfire_bin_lut.argtypes = [vp, vp, C.POINTER(C.c_double)]
     lib.ld_stdrng_key.argtypes = [C.c_uint64, vp]
+    lib.ld_spatial_tile_order.restype = sz
+    lib.ld_spatial_tile_order.argtypes = [vp, sz, vp]
     _lib = lib
     return lib
 
@@ -187,6 +189,17 @@ def dfire_bin_lut():
     d2 = C.c_double()
     _check(load_library().ld_dfire_bin_lut(_ptr(lut), _ptr(steps), C.byref(d2)))
     return lut, steps, d2.value
+
+
+def spatial_tile_order(xyz):
+    """Tile order of the DFIRE kernel: slot -> atom index (UINT32_MAX = padding)."""
+    xyz = _f64(xyz).reshape(-1, 3)
+    n = xyz.shape[0]
+    out = np.zeros((n + 63) // 64 * 64, dtype=np.uint32)
+    got = load_library().ld_spatial_tile_order(_ptr(xyz), n, _ptr(out))
+    if got != out.size:
+        raise LightdockError(-1, load_library().ld_last_error().decode())
+    return out
 
 
 def stdrng_key(seed):

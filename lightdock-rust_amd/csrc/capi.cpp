@@ -15,6 +15,7 @@
 #include "host/docking_model.hpp"
 #include "host/error.hpp"
 #include "host/io.hpp"
+#include "host/spatial_order.hpp"
 #include "lightdock_hip.h"
 #include "scorer.hpp"
 
@@ -161,6 +162,16 @@ int ld_dfire_bin_lut(uint8_t *lut_out, double *steps_out, double *interface_d2_o
         if (steps_out) std::memcpy(steps_out, t.step.data(), 21 * sizeof(double));
         if (interface_d2_out) *interface_d2_out = ld::dfire_interface_d2();
     });
+}
+size_t ld_spatial_tile_order(const double *xyz, size_t n, uint32_t *order_out) {
+    size_t len = 0;
+    guarded([&] {
+        if (!xyz && n) throw ld::Error(LD_ERR_INVALID, "null coordinates");
+        const std::vector<uint32_t> order = ld::spatial_tile_order(xyz, n);
+        if (order_out) std::memcpy(order_out, order.data(), order.size() * sizeof(uint32_t));
+        len = order.size();
+    });
+    return len;
 }
 void ld_stdrng_key(uint64_t seed, uint32_t key_out[8]) { ld::stdrng_key_from_seed(seed, key_out); }
 

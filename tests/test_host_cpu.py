@@ -263,3 +263,35 @@ def test_cli_panics_of_the_reference_exit_101(pkg, orc, tmp_path):
         r = subprocess.run([cli, str(lonely), os.path.join(src, "initial_positions_0.dat"), "1", "dna"], cwd=run,
                            capture_output=True, text=True)
         assert r.returncode == 101 and "Number of read ANM in receptor does not correspond" in r.stderr
+
+
+def test_spatial_tile_order(pkg, orc, table):
+    """host/spatial_order.cpp: a permutation with padding only at the tail, whose 8-atom subtiles
+    and 64-atom tiles are far more compact than file order or random order."""
+    from conftest import case_kwargs
+    method, rec, lig, kw = case_kwargs("1k4c", orc, table)
+    xyz = orc.Scorer(method, rec, lig, **kw).model(0)["coordinates"]
+    n = len(xyz)
+    order = pkg.spatial_tile_order(xyz)
+    assert order.size == (n + 63) // 64 * 64
+    real = order[order != 0xFFFFFFFF]
+    assert np.array_equal(np.sort(real), np.arange(n)) and np.all(order[:n] != 0xFFFFFFFF)
+
+    def diagonals(idx, size):
+        d = []
+        for k in range(0, n - size + 1, size):
+            p = xyz[idx[k:k + size]]
+            d.append(np.linalg.norm(p.max(0) - p.min(0)))
+        return np.array(d)
+
+    rnd = np.random.default_rng(0).permutation(n)
+    file_order = np.arange(n)
+    # an 8-atom leaf is about one residue; no leaf or tile sprawls like the membrane beads do in file order
+    assert np.median(diagonals(real, 8)) < 10.0 < np.median(diagonals(rnd, 8))
+    assert diagonals(real, 8).max() < 0.5 * diagonals(file_order, 8).max()
+    assert diagonals(real, 64).max() < 0.5 * diagonals(file_order, 64).max()
+    assert diagonals(real, 8).mean() < 0.6 * diagonals(file_order, 8).mean()
+    for m in (0, 1, 7, 8, 9, 63, 64, 65, 200):
+        pts = np.random.default_rng(m).normal(size=(m, 3))
+        o = pkg.spatial_tile_order(pts)
+        assert o.size == (m + 63) // 64 * 64 and np.array_equal(np.sort(o[:m]), np.arange(m)) and np.all(o[m:] == 0xFFFFFFFF)
