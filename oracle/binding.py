@@ -160,9 +160,12 @@ class Rng:
         self._h = C.c_void_p(lib().orc_rng_new(seed))
 
     def __del__(self):
-        if self._h:
-            lib().orc_rng_free(self._h)
-            self._h = None
+        try:  # module globals may already be gone at interpreter shutdown
+            if getattr(self, "_h", None):
+                lib().orc_rng_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     def next_u64(self):
         return lib().orc_rng_next_u64(self._h)
@@ -210,9 +213,12 @@ class Scorer:
         self.anm_lig = lig_num_anm if use_anm else 0
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_scorer_free(self._h)
-            self._h = None
+        try:  # module globals may already be gone at interpreter shutdown
+            if getattr(self, "_h", None):
+                lib().orc_scorer_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     @property
     def pose_len(self):
@@ -282,9 +288,12 @@ class GSO:
         self._h = C.c_void_p(h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_gso_free(self._h)
-            self._h = None
+        try:  # module globals may already be gone at interpreter shutdown
+            if getattr(self, "_h", None):
+                lib().orc_gso_free(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     def step(self):
         lib().orc_gso_step(self._h)
