@@ -475,10 +475,11 @@ def test_pydock_method(pkg, orc, scorers, tmp_path):
     hip, cpu = pkg.Scorer.from_pdb("pydock", str(odd), lig), orc.Scorer("pydock", str(odd), lig)
     poses = np.array([[0, 0, 0, 1, 0, 0, 0], [3.0, -2.0, 1.0, 0.5, 0.5, -0.5, 0.5]], dtype=np.float64)
     assert rel_err(hip.energy_batch(poses), cpu.energy_rows(poses)) < REL_TOL
-    # the CLI accepts the third method name
+    # the CLI accepts the third method name; the mode files are given in lightdock's own
+    # (modes, atoms, 3) shape (lightdock_*.nm.npy) instead of lgd_flatten's flat one
     src = os.path.join(GOLDEN, "1azp")
-    for f in ("rec_nm.npy", "lig_nm.npy"):
-        shutil.copy(os.path.join(src, f), tmp_path)
+    for f, atoms in (("rec_nm.npy", 1094), ("lig_nm.npy", 506)):
+        np.save(tmp_path / f, np.load(os.path.join(src, f)).reshape(10, atoms, 3))
     r = subprocess.run([pkg.CLI_PATH, os.path.join(src, "setup.json"), os.path.join(src, "initial_positions_0.dat"),
                         "1", "PyDock"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 0 and "Loading PYDOCK scoring function" in r.stdout
