@@ -478,6 +478,25 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
     if (n == 0) return;
     if (!d_poses || !d_energies) throw Error(LD_ERR_INVALID, "energy_batch: null pose/energy buffer");
     if (stride < pose_len()) throw Error(LD_ERR_INVALID, "energy_batch: stride shorter than a pose row");
+    if (use_tiled_ && rec_anm_per_pose_) {
+        // every pose carries its own deformed receptor image: bound that workspace (8 GiB) by
+        // slicing very large batches; poses are independent, so the results do not change
+        const size_t pad = (size_t)tiled_.rec.n_tiles * 64;
+        const size_t per_pose = pad * sizeof(TiledAtom) + (pad / 8 + pad / 64) * sizeof(TiledBox);
+        static const size_t cap = [] {  // LIGHTDOCK_RECEPTOR_IMAGE_MIB: test hook for the slicing
+            const char *e = std::getenv("LIGHTDOCK_RECEPTOR_IMAGE_MIB");
+            const long v = e ? std::atol(e) : 0;
+            return v > 0 ? size_t(v) << 20 : size_t(8) << 30;
+        }();
+        const size_t max_n = std::max<size_t>(1, cap / per_pose);
+        if (n > max_n) {
+            for (size_t off = 0; off < n; off += max_n)
+                energy_batch_device(std::min(max_n, n - off), d_poses + off * stride, stride,
+                                    d_active ? d_active + off : nullptr, d_energies + off,
+                                    d_pair_counts ? d_pair_counts + off : nullptr);
+            return;
+        }
+    }
     reserve_workspace(n, d_pair_counts != nullptr);
 
     PairLaunch p = pair_;

@@ -442,6 +442,32 @@ def test_gso_dfire_with_anm_2uuy(pkg, scorers, orc):
     assert np.max(np.abs(a["poses"] - b["poses"])) < 1e-12
 
 
+def test_receptor_anm_batch_slicing(pkg, scorers, orc, tmp_path):
+    """With receptor ANM every pose carries its own receptor image; very large batches are cut
+    into slices so that workspace stays bounded.  A child process with the bound lowered to
+    1 MiB (a handful of poses per slice) must return bit-identical energies."""
+    hip, _ = scorers("2uuy")
+    poses = case_positions("2uuy", orc)
+    want = hip.energy_batch(poses)
+    np.save(tmp_path / "poses.npy", poses)
+    code = (
+        "import sys, os, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "from conftest import case_kwargs\n"
+        "import torch; torch.cuda.init()\n"
+        "pkg, orc = ge.package(), ge.oracle(); pkg.init(0)\n"
+        "m, rec, lig, kw = case_kwargs('2uuy', orc, pkg.synth.dcparams())\n"
+        "s = pkg.Scorer.from_pdb(m, rec, lig, **kw)\n"
+        "np.save(%r, s.energy_batch(np.load(%r)))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+         str(tmp_path / "sliced.npy"), str(tmp_path / "poses.npy"))
+    env = dict(os.environ, LIGHTDOCK_RECEPTOR_IMAGE_MIB="1")
+    r = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(tmp_path / "sliced.npy"), want)
+
+
 @pytest.mark.timeout(900)
 def test_cli_100_steps_matches_reference_files_1azp(pkg, tmp_path):
     """The full published run of the example: 100 steps, all 11 gso files against the files the
