@@ -30,6 +30,33 @@ def test_no_torch_types_in_the_abi(pkg):
     assert "torch" not in header and "at::" not in header and "std::" not in header
 
 
+def test_header_is_plain_c_and_a_c_program_links(pkg, orc, tmp_path):
+    """The boundary is a C ABI: the header compiles as C99 and a C program links against the
+    shared library (host-only entry points; nothing here touches a GPU)."""
+    src = tmp_path / "link.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "lightdock_hip.h"\n'
+        "int main(void) {\n"
+        "  uint32_t key[8]; uint8_t lut[901]; double steps[21], iface;\n"
+        "  ld_stdrng_key(324324u, key);\n"
+        "  if (ld_dfire_bin_lut(lut, steps, &iface) != LD_OK) return 2;\n"
+        '  printf("%u %u %.17g %s\\n", (unsigned)key[0], (unsigned)lut[899], iface, ld_version());\n'
+        "  return ld_scorer_create(NULL) == NULL && ld_last_error()[0] ? 0 : 3;\n"
+        "}\n")
+    lib_dir = os.path.dirname(pkg.LIB_PATH)
+    exe = tmp_path / "link"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", pkg.INCLUDE_DIR, str(src),
+                        "-L", lib_dir, "-llightdock_hip", "-Wl,-rpath," + lib_dir, "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    key0, last_bin, iface, version = r.stdout.split(None, 3)
+    assert int(key0) == int(pkg.stdrng_key(324324)[0])
+    assert int(last_bin) & 31 == 19 and float(iface) == pkg.dfire_bin_lut()[2]
+    assert "gfx950" in version
+
+
 @pytest.mark.parametrize("name", ["1ppe", "1k4c", "2uuy", "1azp"])
 def test_host_model_builder_matches_oracle(pkg, orc, table, name):
     c, d, rec, lig = case_paths(name)
