@@ -52,6 +52,27 @@ class _ScorerDesc(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 and ask for
+    it by the name "libamdhip64.so"; this library asks for the soname "libamdhip64.so.7".  If
+    torch is imported first both resolve to torch's copy, but the other way round the process
+    would end up with two runtimes (and torch then reports no GPU).  So when a torch wheel with
+    a bundled runtime is installed and not loaded yet, load that copy first; without torch the
+    system runtime under /opt/rocm is used, as by the lightdock-hip binary."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.origin:
+            bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(bundled):
+                C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass
+
+
 def load_library():
     """dlopen the in-tree HIP library; fail loudly when it has not been built."""
     global _lib
@@ -60,6 +81,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
                           "there is no CPU fallback for the pose-energy path" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     vp, sz, dp = C.c_void_p, C.c_size_t, C.POINTER(C.c_double)
     lib.ld_last_error.restype = C.c_char_p

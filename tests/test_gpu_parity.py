@@ -442,6 +442,19 @@ def test_gso_dfire_with_anm_2uuy(pkg, scorers, orc):
     assert np.max(np.abs(a["poses"] - b["poses"])) < 1e-12
 
 
+def test_library_before_torch_shares_one_hip_runtime():
+    """Loading the HIP library before PyTorch must not leave two HIP runtimes in the process
+    (torch would then report no GPU): tools/check_load_order.py runs smoke(), then imports
+    torch, runs an op and lists the libamdhip64 copies mapped."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.sys.executable, os.path.join(root, "tools", "check_load_order.py")], capture_output=True,
+                       text=True, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "smoke ok" in r.stdout and "cuda available True" in r.stdout and "torch op 140.0" in r.stdout
+    mapped = r.stdout.split("hip runtimes mapped:")[1]
+    assert mapped.count("libamdhip64") == 1, mapped
+
+
 def test_receptor_anm_batch_slicing(pkg, scorers, orc, tmp_path):
     """With receptor ANM every pose carries its own receptor image; very large batches are cut
     into slices so that workspace stays bounded.  A child process with the bound lowered to
