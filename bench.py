@@ -137,6 +137,10 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if rank == 0:
+        ge.ensure_built()
+    if dist is not None:
+        dist.barrier()
     pkg = ge.package()
     pkg.init(local)
     case = load_case(pkg, args.workload)

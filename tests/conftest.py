@@ -14,10 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _build_if_missing():
+    import __graft_entry__ as ge
+    ge.ensure_built()
+
+
 @pytest.fixture(scope="session")
 def orc():
     """CPU oracle binding (the checker)."""
     import __graft_entry__ as ge
+    _build_if_missing()
     o = ge.oracle()
     o.lib()
     return o
@@ -27,9 +33,9 @@ def orc():
 def pkg():
     """The product package, lightdock-rust_amd/ (C ABI via ctypes)."""
     import __graft_entry__ as ge
-    # torch bundles its own HIP runtime; when both live in one process torch has to come up
-    # first or it finds "No HIP GPUs".  Only matters for the GPU tests that borrow torch for
-    # device buffers; the product itself never imports torch.
+    _build_if_missing()
+    # GPU tests borrow torch for device buffers; bring it up first so that every test sees the
+    # same, already initialised runtime (the library shares torch's HIP runtime either way).
     try:
         import torch
         if torch.cuda.is_available():
