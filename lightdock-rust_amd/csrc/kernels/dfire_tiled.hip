@@ -53,6 +53,7 @@ __device__ __forceinline__ Quat qinverse(const Quat &q) {  // src/qt.rs:48-50
 // bit for bit in IEEE arithmetic (power-of-two scaling commutes with rounding), so
 // D = 4 * d2 exactly, the cutoff d2 <= 225 is D <= 900, and DFIRE's 0.25 A^2 binning cell is
 // simply (int)D -- one conversion, no multiply.
+constexpr int kSliceRecords = 64 + 64 + 8;  // per wave: ligand tile, receptor tile, one far-away receptor subtile
 constexpr double kCutScaled = 900.0;       // 4 * 15^2, src/dfire.rs:334
 constexpr float kCut2Padded = 900.04f;     // the same for the f32 box tests, padded for their rounding
 
@@ -97,7 +98,6 @@ __device__ __forceinline__ TiledBox to_box(const BoxRegs &b) {
     return TiledBox{b.lox, b.loy, b.loz, 0.f, b.hix, b.hiy, b.hiz, 0.f};
 }
 
-__device__ __forceinline__ size_t round16(size_t v) { return (v + 15) & ~size_t(15); }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -149,7 +149,6 @@ __global__ __launch_bounds__(64) void dfire_prepare_receptor(const PrepareRecept
 // Pair kernel
 // ---------------------------------------------------------------------------------------------
 struct PairCtx {
-    const uint8_t *lut;      // cell -> bin | 0x40 (pair may be "interface") | 0x80 (a bin step falls inside the cell)
     const double *bin_step;  // scaled by 4
     double iface_scaled;     // 4 * iface_d2
     uint32_t *pose_flags;
@@ -181,15 +180,25 @@ __device__ __forceinline__ void read_record(const TiledAtom *p, RecLo &lo, RecHi
     hi.slot = (int32_t)(bits >> 32);
 }
 
-// the rare tail of a pair: exact position of a bin step inside the cell, interface flags
-__device__ __forceinline__ uint32_t pair_slow_path(const PairCtx &c, uint32_t code, double D, int32_t lslot, int32_t rslot) {
-    uint32_t bin = code & 0x1fu;
-    if (code & 0x80u) bin += D >= c.bin_step[bin + 1] ? 1u : 0u;
-    if ((code & 0x40u) && D <= c.iface_scaled) {  // d <= 3.9 (src/dfire.rs:339-342)
+// the rare tail of a pair (LUT word flagged kTiledLutSlow): the cutoff itself, the exact position
+// of a bin step inside the cell, interface flags.  Returns the pair's LUT term.
+__device__ __forceinline__ uint32_t pair_slow_path(const PairCtx &c, uint32_t word, double D, int32_t lslot, int32_t rslot) {
+    if (!(D <= kCutScaled)) return kTiledLutMiss;  // d2 <= 225 (src/dfire.rs:334)
+    uint32_t bin = word & 0x1fu;
+    if (word & 0x80u) bin += D >= c.bin_step[bin + 1] ? 1u : 0u;
+    if ((word & 0x40u) && D <= c.iface_scaled) {  // d <= 3.9 (src/dfire.rs:339-342)
         if (rslot >= 0) atomicOr(&c.pose_flags[rslot >> 5], 1u << (rslot & 31));
         if (lslot >= 0) atomicOr(&c.pose_flags[c.rec_flag_words + (lslot >> 5)], 1u << (lslot & 31));
     }
-    return bin;
+    return tiled_bin_term(bin);
+}
+
+// potential[...] through a raw buffer: the offset is 32-bit (no 64-bit address arithmetic) and an
+// offset past the end (kTiledLutMiss) reads 0.0 without a memory request
+typedef unsigned int vec2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double table_entry(__amdgpu_buffer_rsrc_t table, uint32_t byte_offset) {
+    const vec2u v = __builtin_amdgcn_raw_buffer_load_b64(table, (int)byte_offset, 0, 0);
+    return __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
 }
 
 // MAXT/MINW = launch bounds.  Capping registers at 64 (8 waves per SIMD) was measured SLOWER on
@@ -198,15 +207,15 @@ template <bool COUNT, int MAXT, int MINW>
 __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunch T) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // ---- LDS carve (every offset a multiple of 16) ---------------------------------------
-    uint8_t *lut = smem;
-    size_t off = round16(kDfireLutCells);
+    uint32_t *lut = reinterpret_cast<uint32_t *>(smem);
+    size_t off = kDfireLutCells * sizeof(uint32_t);
     double *bin_step = reinterpret_cast<double *>(smem + off);
     off += kDfireSteps * sizeof(double);
     double *red = reinterpret_cast<double *>(smem + off);
     off += kTiledMaxWaves * sizeof(double);
     uint32_t *red_cnt = reinterpret_cast<uint32_t *>(smem + off);  // [kTiledMaxWaves][2]
     off += kTiledMaxWaves * 2 * sizeof(uint32_t);
-    TiledAtom *slices = reinterpret_cast<TiledAtom *>(smem + off);  // per wave: 64 ligand + 64 receptor records
+    TiledAtom *slices = reinterpret_cast<TiledAtom *>(smem + off);  // per wave: kSliceRecords records
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -222,12 +231,11 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
     const int group = (int)(item_id % (unsigned)T.n_groups);
     if (T.active != nullptr && T.active[pose] == 0) return;
 
-    for (int i = tid; i < kDfireLutCells / 4; i += blockDim.x)
-        reinterpret_cast<uint32_t *>(lut)[i] = reinterpret_cast<const uint32_t *>(T.lut)[i];
+    for (int i = tid; i < kDfireLutCells; i += blockDim.x) lut[i] = T.lut[i];
     if (tid < kDfireSteps) bin_step[tid] = 4.0 * T.bin_step[tid];  // scaled coordinates
     __syncthreads();
 
-    TiledAtom *ligt = slices + wave * 128;
+    TiledAtom *ligt = slices + wave * kSliceRecords;
     TiledAtom *rect = ligt + 64;
     const int li = lane >> 3, lj = lane & 7;
     double acc = 0.0, pend0 = 0.0, pend1 = 0.0;
@@ -273,17 +281,27 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
             me.slot = T.lig.slot[la];
         }
         ligt[lane] = me;
+        if (lane < 8) {  // receptor subtile no pair can reach: partner of an odd leftover block
+            TiledAtom far;
+            far.x = -1.0e30;
+            far.y = 0.0;
+            far.z = 0.0;
+            far.tindex = 0;
+            far.slot = -1;
+            rect[64 + lane] = far;
+        }
         BoxRegs sub = point_box(valid, me.x, me.y, me.z);
         box_butterfly<1, 8>(sub);  // lanes 8a..8a+7 now hold the box of ligand subtile a
         BoxRegs whole = sub;
         box_butterfly<8, 64>(whole);
 
         PairCtx ctx;
-        ctx.lut = lut;
         ctx.bin_step = bin_step;
         ctx.iface_scaled = 4.0 * T.iface_d2;
         ctx.pose_flags = T.flags + pose * (size_t)(T.rec.flag_words + T.lig.flag_words);
         ctx.rec_flag_words = T.rec.flag_words;
+        const __amdgpu_buffer_rsrc_t table = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double *>(T.table), 0, (int)(kTiledTableDoubles * sizeof(double)), 0x00020000);
 
         // ---- 2. receptor tiles, 64 per ballot ---------------------------------------------------
         for (int base = 0; base < T.rec.n_tiles; base += 64) {
@@ -322,28 +340,27 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
                     const int k0 = __ffsll(smask) - 1;
                     smask &= smask - 1;
                     const bool two = smask != 0;
-                    const int k1 = two ? __ffsll(smask) - 1 : k0;
+                    const int k1 = two ? __ffsll(smask) - 1 : 0;
                     smask &= smask - 1;  // 0 stays 0
+                    const int rsub1 = two ? (k1 & 7) * 8 : 64;  // odd leftover: the far-away subtile, every pair misses
                     RecLo L0lo, L1lo, R0lo, R1lo;
                     RecHi L0hi, L1hi, R0hi, R1hi;
                     read_record(&ligt[(k0 >> 3) * 8 + li], L0lo, L0hi);
                     read_record(&rect[(k0 & 7) * 8 + lj], R0lo, R0hi);
                     read_record(&ligt[(k1 >> 3) * 8 + li], L1lo, L1hi);
-                    read_record(&rect[(k1 & 7) * 8 + lj], R1lo, R1hi);
+                    read_record(&rect[rsub1 + lj], R1lo, R1hi);
                     // (x1 - la[0])^2 + (y1 - la[1])^2 + (z1 - la[2])^2, src/dfire.rs:331-333 (x4)
                     const double dx0 = R0lo.x - L0lo.x, dy0 = R0lo.y - L0lo.y, dz0 = R0hi.z - L0hi.z;
                     const double dx1 = R1lo.x - L1lo.x, dy1 = R1lo.y - L1lo.y, dz1 = R1hi.z - L1hi.z;
                     const double D0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
                     const double D1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
-                    const bool hit0 = D0 <= kCutScaled;
-                    const bool hit1 = two && D1 <= kCutScaled;
-                    const uint32_t code0 = lut[min((unsigned)(int)D0, 903u)];
-                    const uint32_t code1 = lut[min((unsigned)(int)D1, 903u)];
-                    uint32_t bin0 = code0 & 0x1fu, bin1 = code1 & 0x1fu;
-                    const bool slow0 = hit0 && (code0 & 0xc0u), slow1 = hit1 && (code1 & 0xc0u);
+                    // cell -> table term; cells past the cutoff give kTiledLutMiss (no compare on D)
+                    uint32_t t0 = lut[min((unsigned)(int)D0, (unsigned)(kDfireLutCells - 1))];
+                    uint32_t t1 = lut[min((unsigned)(int)D1, (unsigned)(kDfireLutCells - 1))];
+                    const bool slow0 = (int)t0 >= (int)kTiledLutSlow, slow1 = (int)t1 >= (int)kTiledLutSlow;
                     if (__builtin_expect(slow0 || slow1, 0)) {
-                        if (slow0) bin0 = pair_slow_path(ctx, code0, D0, L0hi.slot, R0hi.slot);
-                        if (slow1) bin1 = pair_slow_path(ctx, code1, D1, L1hi.slot, R1hi.slot);
+                        if (slow0) t0 = pair_slow_path(ctx, t0, D0, L0hi.slot, R0hi.slot);
+                        if (slow1) t1 = pair_slow_path(ctx, t1, D1, L1hi.slot, R1hi.slot);
                     }
                     // retire the previous iteration's gathers only now, so their L2 latency hides
                     // behind this iteration's LDS reads and arithmetic; the asm pins the order
@@ -351,11 +368,9 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
                     acc += pend0;
                     acc += pend1;
                     asm volatile("" : "+v"(acc) : : "memory");
-                    pend0 = 0.0;
-                    pend1 = 0.0;
-                    if (hit0) pend0 = T.table[L0hi.tindex + bin0 * kTiledTableStride + R0hi.tindex];  // src/dfire.rs:338, re-laid out
-                    if (hit1) pend1 = T.table[L1hi.tindex + bin1 * kTiledTableStride + R1hi.tindex];
-                    if (COUNT) cnt += (hit0 ? 1u : 0u) + (hit1 ? 1u : 0u);
+                    pend0 = table_entry(table, L0hi.tindex + R0hi.tindex + t0);  // src/dfire.rs:338, re-laid out
+                    pend1 = table_entry(table, L1hi.tindex + R1hi.tindex + t1);
+                    if (COUNT) cnt += (t0 < kTiledLutSlow ? 1u : 0u) + (t1 < kTiledLutSlow ? 1u : 0u);
                 }
             }
         }
@@ -397,9 +412,9 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
 }  // namespace
 
 size_t tiled_kernel_lds_bytes(const TiledLaunch &t) {
-    size_t b = ((kDfireLutCells + 15) & ~15) + kDfireSteps * sizeof(double);
+    size_t b = kDfireLutCells * sizeof(uint32_t) + kDfireSteps * sizeof(double);
     b += kTiledMaxWaves * sizeof(double) + kTiledMaxWaves * 2 * sizeof(uint32_t);
-    b += (size_t)t.waves * 128 * sizeof(TiledAtom);
+    b += (size_t)t.waves * kSliceRecords * sizeof(TiledAtom);
     return b;
 }
 

@@ -15,19 +15,39 @@
 namespace ld {
 
 constexpr int kTiledMaxWaves = 16;
-// The tiled kernel reads the potential as table[lig_type][bin 0..20][rec_type] (stride 176):
-// the 8 receptor atoms of a subtile are mostly one residue, whose DFIRE types are consecutive
-// numbers, so lanes of one ligand atom whose pairs fall in the same distance bin share a 64-byte
-// line.  The kernel is bound by outstanding L1 misses of this gather, so fewer
-// distinct lines per wave instruction is throughput.  Entry [l][20][r] is what the reference
-// reads for r = 15.0 A exactly: potential[r*3380 + l*20 + 20] (src/dfire.rs:338).
-constexpr uint32_t kTiledTableStride = 176;
+// The tiled kernel reads the potential in 128-byte patches of 2 ligand types x 2 receptor types
+// x 4 distance bins:
+//   index = ((l/2)*84 + r/2)*96 + (bin/4)*16 + (l%2)*8 + (r%2)*4 + bin%4        (bin 0..20)
+// The atoms of a subtile are mostly one residue, whose DFIRE types are consecutive numbers, and
+// bonded atoms sit in the same or the next distance bin of a given partner, so the hits of one
+// 8x8 block fall into fewer distinct cache lines than with any row-major order (simulated on the
+// 1k4c poses: 0.63 lines per hit; [lig][bin][rec] rows 0.77, the reference's [rec][lig][bin] 0.95).
+// The kernel is bound by the L1 fills of this gather, so lines per hit is throughput.
+// Bin 20 is what the reference reads for r = 15.0 A exactly: potential[r*3380 + l*20 + 20]
+// (src/dfire.rs:338).
 constexpr uint32_t kTiledTableBins = 21;
+constexpr uint32_t kTiledPatchDoubles = 16;                       // one 128-byte line
+constexpr uint32_t kTiledRecStride = 6 * kTiledPatchDoubles;      // 24 bin slots per type pair
+constexpr uint32_t kTiledLigStride = 85 * kTiledRecStride;        // 169 types -> 85 pairs
+constexpr uint32_t kTiledTableDoubles = 85 * kTiledLigStride;
+// The three terms are BYTE offsets; their sum is the buffer-load offset of the table entry.
+__host__ __device__ inline uint32_t tiled_lig_term(uint32_t type) { return 8u * ((type >> 1) * kTiledLigStride + (type & 1u) * 8u); }
+__host__ __device__ inline uint32_t tiled_rec_term(uint32_t type) { return 8u * ((type >> 1) * kTiledRecStride + (type & 1u) * 4u); }
+__host__ __device__ inline uint32_t tiled_bin_term(uint32_t bin) { return 8u * (bin + 12u * (bin >> 2)); }
+// Cell LUT of the kernel: one 32-bit word per 0.25 A^2 cell of d2 (cell = (int)(4 d2), 0..903)
+//   cells whose every d2 has one bin and no side effect:  tiled_bin_term(bin)
+//   cells that need the exact test (a bin step inside, the interface distance, the cutoff
+//   cell 900):                                            kTiledLutSlow | 8-bit code (scorer.cpp)
+//   cells beyond the cutoff:                              kTiledLutMiss
+// kTiledLutMiss pushes the buffer offset past the end of the table: the load returns 0.0 without
+// touching memory, so pairs out of range need neither a compare nor a branch.
+constexpr uint32_t kTiledLutSlow = 0x40000000u;
+constexpr uint32_t kTiledLutMiss = 0x80000000u;
 
 // 32-byte atom record, the unit both molecules are handled in inside the kernel.
 struct alignas(16) TiledAtom {
     double x, y, z;
-    uint32_t tindex;  // receptor: type, ligand: type * 21 * 176 (see kTiledTableStride)
+    uint32_t tindex;  // tiled_rec_term(type) / tiled_lig_term(type): byte offsets
     int32_t slot;     // interface-flag bit or -1
 };
 static_assert(sizeof(TiledAtom) == 32, "TiledAtom must be 32 bytes");
@@ -73,7 +93,7 @@ struct TiledLaunch {
     int split = 1;        // waves sharing one ligand tile (each takes every split-th surviving receptor tile)
     int n_groups = 0;     // workgroups per pose = ceil(lig.n_tiles * split / waves)
     const double *table = nullptr;
-    const uint8_t *lut = nullptr;      // cell -> bin | 0x80 if a bin step falls inside the cell
+    const uint32_t *lut = nullptr;     // kDfireLutCells words, see kTiledLutSlow
     const double *bin_step = nullptr;  // kDfireSteps
     double iface_d2 = 0.0;
     const double *poses = nullptr;

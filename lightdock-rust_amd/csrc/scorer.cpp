@@ -320,7 +320,7 @@ void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, Tiled
         x[i] = m.coordinates[3 * (size_t)a];
         y[i] = m.coordinates[3 * (size_t)a + 1];
         z[i] = m.coordinates[3 * (size_t)a + 2];
-        t[i] = is_receptor ? m.dfire_types[a] : m.dfire_types[a] * kTiledTableBins * kTiledTableStride;
+        t[i] = is_receptor ? tiled_rec_term(m.dfire_types[a]) : tiled_lig_term(m.dfire_types[a]);
         slot[i] = hslot[a];
     }
     out.n_real = (int)n;
@@ -363,12 +363,12 @@ void Scorer::build_tiled(const ld_scorer_desc &desc) {
     tiled_.rec.flag_words = pair_.rec.flag_words;
     tiled_.use_anm = use_anm_ ? 1 : 0;
     tiled_.anm_rec = (int)anm_rec();
-    {   // potential re-laid out as [lig type][bin 0..20][rec type], see dfire_tiled.hpp
-        std::vector<double> t2((size_t)169 * kTiledTableBins * kTiledTableStride, 0.0);
+    {   // potential re-laid out in 2 x 2 x 4 patches, see dfire_tiled.hpp
+        std::vector<double> t2(kTiledTableDoubles, 0.0);
         for (uint32_t l = 0; l < 168; l++)
             for (uint32_t b = 0; b < kTiledTableBins; b++)
                 for (uint32_t r = 0; r < 168; r++)
-                    t2[((size_t)l * kTiledTableBins + b) * kTiledTableStride + r] = desc.potential[(size_t)r * kDfireRowStride + l * 20 + b];
+                    t2[(tiled_lig_term(l) + tiled_rec_term(r) + tiled_bin_term(b)) / 8] = desc.potential[(size_t)r * kDfireRowStride + l * 20 + b];
         tiled_.table = arena_.upload(t2);
     }
     tiled_.bin_step = pair_.bin_step;
@@ -382,8 +382,10 @@ void Scorer::build_tiled(const ld_scorer_desc &desc) {
             if (b.step[bin + 1] < (c + 1) * 0.25) code[c] |= 0x80u;
             if (c * 0.25 <= pair_.iface_d2) code[c] |= 0x40u;
         }
-        for (int c = 901; c < kDfireLutCells; c++) code[c] = 0;
-        tiled_.lut = arena_.upload(code);
+        std::vector<uint32_t> words(kDfireLutCells, kTiledLutMiss);
+        for (int c = 0; c <= 900; c++)  // cell 900 holds the cutoff itself: d2 = 225 is in, the rest of the cell out
+            words[c] = (code[c] & 0xc0u) || c == 900 ? kTiledLutSlow | code[c] : tiled_bin_term(code[c]);
+        tiled_.lut = arena_.upload(words);
     }
     int waves = 4;  // measured on MI355X (1k4c, 1ppe): 4 waves per workgroup beat 1, 2 and 8
     if (const char *e = std::getenv("LIGHTDOCK_TILED_WAVES")) {
