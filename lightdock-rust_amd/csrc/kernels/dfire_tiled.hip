@@ -53,7 +53,7 @@ __device__ __forceinline__ Quat qinverse(const Quat &q) {  // src/qt.rs:48-50
 // bit for bit in IEEE arithmetic (power-of-two scaling commutes with rounding), so
 // D = 4 * d2 exactly, the cutoff d2 <= 225 is D <= 900, and DFIRE's 0.25 A^2 binning cell is
 // simply (int)D -- one conversion, no multiply.
-constexpr int kSliceRecords = 64 + 64 + 8;  // per wave: ligand tile, receptor tile, one far-away receptor subtile
+constexpr int kSliceRecords = 64 + 64;  // per wave: ligand tile, receptor tile
 constexpr double kCutScaled = 900.0;       // 4 * 15^2, src/dfire.rs:334
 constexpr float kCut2Padded = 900.04f;     // the same for the f32 box tests, padded for their rounding
 
@@ -211,11 +211,11 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
     size_t off = kDfireLutCells * sizeof(uint32_t);
     double *bin_step = reinterpret_cast<double *>(smem + off);
     off += kDfireSteps * sizeof(double);
-    double *red = reinterpret_cast<double *>(smem + off);
-    off += kTiledMaxWaves * sizeof(double);
-    uint32_t *red_cnt = reinterpret_cast<uint32_t *>(smem + off);  // [kTiledMaxWaves][2]
-    off += kTiledMaxWaves * 2 * sizeof(uint32_t);
+    TiledAtom *far_subtile = reinterpret_cast<TiledAtom *>(smem + off);  // 8 records no pair can reach
+    off += 8 * sizeof(TiledAtom);
     TiledAtom *slices = reinterpret_cast<TiledAtom *>(smem + off);  // per wave: kSliceRecords records
+    // 3616 + 192 + 256 + 4 x 4096 = 20 448 bytes for 4 waves: 8 workgroups (32 waves) per CU.  The
+    // per-wave results of the final reduction reuse the first 16 bytes of each wave's own slice.
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -231,12 +231,24 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
     const int group = (int)(item_id % (unsigned)T.n_groups);
     if (T.active != nullptr && T.active[pose] == 0) return;
 
-    for (int i = tid; i < kDfireLutCells; i += blockDim.x) lut[i] = T.lut[i];
+    // 904 words = 226 x 16 bytes: one load per thread and one round trip for a 256-thread workgroup
+    for (int i = tid; i < kDfireLutCells / 4; i += blockDim.x)
+        reinterpret_cast<uint4 *>(lut)[i] = reinterpret_cast<const uint4 *>(T.lut)[i];
     if (tid < kDfireSteps) bin_step[tid] = 4.0 * T.bin_step[tid];  // scaled coordinates
+    if (tid < 8) {  // partner of an odd leftover block: every pair misses
+        TiledAtom far;
+        far.x = -1.0e30;
+        far.y = 0.0;
+        far.z = 0.0;
+        far.tindex = 0;
+        far.slot = -1;
+        far_subtile[tid] = far;
+    }
     __syncthreads();
 
     TiledAtom *ligt = slices + wave * kSliceRecords;
     TiledAtom *rect = ligt + 64;
+    const int far_off = (int)(far_subtile - rect);  // in records, relative to this wave's receptor tile (negative)
     const int li = lane >> 3, lj = lane & 7;
     double acc = 0.0, pend0 = 0.0, pend1 = 0.0;
     uint32_t cnt = 0, tested = 0;
@@ -281,15 +293,6 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
             me.slot = T.lig.slot[la];
         }
         ligt[lane] = me;
-        if (lane < 8) {  // receptor subtile no pair can reach: partner of an odd leftover block
-            TiledAtom far;
-            far.x = -1.0e30;
-            far.y = 0.0;
-            far.z = 0.0;
-            far.tindex = 0;
-            far.slot = -1;
-            rect[64 + lane] = far;
-        }
         BoxRegs sub = point_box(valid, me.x, me.y, me.z);
         box_butterfly<1, 8>(sub);  // lanes 8a..8a+7 now hold the box of ligand subtile a
         BoxRegs whole = sub;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
                     const bool two = smask != 0;
                     const int k1 = two ? __ffsll(smask) - 1 : 0;
                     smask &= smask - 1;  // 0 stays 0
-                    const int rsub1 = two ? (k1 & 7) * 8 : 64;  // odd leftover: the far-away subtile, every pair misses
+                    const int rsub1 = two ? (k1 & 7) * 8 : far_off;  // odd leftover: the far-away subtile, every pair misses
                     RecLo L0lo, L1lo, R0lo, R1lo;
                     RecHi L0hi, L1hi, R0hi, R1hi;
                     read_record(&ligt[(k0 >> 3) * 8 + li], L0lo, L0hi);
@@ -381,23 +384,27 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
     acc += pend1;
     acc = wave_sum(acc);
     if (COUNT) cnt = wave_sum_u32(cnt);
-    if (lane == 0) {
-        red[wave] = acc;
-        if (COUNT) {
-            red_cnt[2 * wave] = cnt;
-            red_cnt[2 * wave + 1] = tested;
-        }
+    struct WaveResult {
+        double sum;
+        uint32_t count, tested;
+    };
+    static_assert(sizeof(WaveResult) == 16, "WaveResult overlays the head of a slice");
+    if (lane == 0) {  // this wave is done with its slice
+        WaveResult r;
+        r.sum = acc;
+        r.count = cnt;
+        r.tested = tested;
+        *reinterpret_cast<WaveResult *>(ligt) = r;
     }
     __syncthreads();
     if (tid == 0) {
         double s = 0.0;
         uint32_t c = 0, t = 0;
         for (int w = 0; w < T.waves; w++) {
-            s += red[w];
-            if (COUNT) {
-                c += red_cnt[2 * w];
-                t += red_cnt[2 * w + 1];
-            }
+            const WaveResult r = *reinterpret_cast<const WaveResult *>(slices + w * kSliceRecords);
+            s += r.sum;
+            c += r.count;
+            t += r.tested;
         }
         const size_t slot = pose * (size_t)T.n_groups + group;
         T.partial[2 * slot] = s;
@@ -412,8 +419,7 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
 }  // namespace
 
 size_t tiled_kernel_lds_bytes(const TiledLaunch &t) {
-    size_t b = kDfireLutCells * sizeof(uint32_t) + kDfireSteps * sizeof(double);
-    b += kTiledMaxWaves * sizeof(double) + kTiledMaxWaves * 2 * sizeof(uint32_t);
+    size_t b = kDfireLutCells * sizeof(uint32_t) + kDfireSteps * sizeof(double) + 8 * sizeof(TiledAtom);
     b += (size_t)t.waves * kSliceRecords * sizeof(TiledAtom);
     return b;
 }
