@@ -76,6 +76,9 @@ __device__ __forceinline__ float round_up(double v) {
 __device__ __forceinline__ float axis_gap(float lo_a, float hi_a, float lo_b, float hi_b) {
     return fmaxf(0.0f, fmaxf(lo_a - hi_b, lo_b - hi_a));
 }
+__device__ __forceinline__ float uniform_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
 struct BoxRegs {
     float lox, loy, loz, hix, hiy, hiz;
 };
@@ -229,13 +232,26 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Block id -> (pose, group) through a multiplicative permutation.  The ligand tiles at the
+    // Block id -> (pose, group) through a pseudo-random permutation.  The ligand tiles at the
     // interface carry most of the work; the hardware deals block ids round-robin to XCDs and
-    // CUs, and with the plain pose-major order throughput swung by +-20 % with the parity of
-    // groups-per-pose (the same heavy group index kept landing on the same XCDs/CUs).  Scattering
-    // the items gives every XCD and CU the same mix of heavy and light workgroups at all times.
+    // CUs, and with the plain pose-major order (or any map that keeps the low bits of the block
+    // id in the group index, e.g. a multiplicative one when groups-per-pose is a power of two)
+    // the same heavy group keeps landing on the same XCDs: measured up to 2x slower.  The
+    // permutation is a bijective mixer on the next power of two, cycle-walked into [0, total):
+    // every XCD and CU sees the same mix of heavy and light workgroups at all times.
     const unsigned long long total_items = (unsigned long long)T.n_poses * (unsigned)T.n_groups;
-    const unsigned long long item_id = ((unsigned long long)blockIdx.x * 2654435761ull) % total_items;  // prime > total: a bijection
+    unsigned long long item_id = blockIdx.x;
+    {
+        const int bits = 64 - __builtin_clzll(total_items | 1ull);  // total_items < 2^bits
+        const unsigned long long mask = (1ull << bits) - 1ull;
+        const int half = (bits + 1) / 2;
+        do {  // each step is a bijection on `bits`-bit numbers; expected < 2 rounds
+            item_id = (item_id * 0x9E3779B97F4A7C15ull) & mask;
+            item_id ^= item_id >> half;
+            item_id = (item_id * 0xD6E8FEB86659FD93ull) & mask;
+            item_id ^= item_id >> half;
+        } while (item_id >= total_items);
+    }
     const size_t pose = (size_t)(item_id / (unsigned)T.n_groups);
     const int group = (int)(item_id % (unsigned)T.n_groups);
     if (T.active != nullptr && T.active[pose] == 0) return;
@@ -306,10 +322,14 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
         box_butterfly<1, 8>(sub);  // lanes 8a..8a+7 now hold the box of ligand subtile a
         BoxRegs whole = sub;
         box_butterfly<8, 64>(whole);
+        // the tile box is the same in every lane: keep it in scalar registers (6 VGPRs less across
+        // the loops below; the kernel sits exactly at the 64 VGPRs that allow 8 waves per SIMD)
+        whole.lox = uniform_f32(whole.lox); whole.loy = uniform_f32(whole.loy); whole.loz = uniform_f32(whole.loz);
+        whole.hix = uniform_f32(whole.hix); whole.hiy = uniform_f32(whole.hiy); whole.hiz = uniform_f32(whole.hiz);
 
         PairCtx ctx;
         ctx.bin_step = bin_step;
-        ctx.iface_scaled = 4.0 * T.iface_d2;
+        ctx.iface_scaled = T.iface_scaled;  // 4 * iface_d2, from the host: a kernel argument stays in SGPRs
         ctx.pose_flags = T.flags + pose * (size_t)(T.rec.flag_words + T.lig.flag_words);
         ctx.rec_flag_words = T.rec.flag_words;
         const __amdgpu_buffer_rsrc_t table = __builtin_amdgcn_make_buffer_rsrc(

@@ -96,6 +96,7 @@ struct TiledLaunch {
     const uint32_t *lut = nullptr;     // kDfireLutCells words, see kTiledLutSlow
     const double *bin_step = nullptr;  // kDfireSteps
     double iface_d2 = 0.0;
+    double iface_scaled = 0.0;  // 4 * iface_d2 (the kernel works on doubled coordinates)
     const double *poses = nullptr;
     size_t stride = 0;
     const uint8_t *active = nullptr;

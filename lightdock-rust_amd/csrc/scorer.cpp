@@ -373,6 +373,7 @@ void Scorer::build_tiled(const ld_scorer_desc &desc) {
     }
     tiled_.bin_step = pair_.bin_step;
     tiled_.iface_d2 = pair_.iface_d2;
+    tiled_.iface_scaled = 4.0 * pair_.iface_d2;
     {   // cell code = bin at the cell's lower edge | 0x80 when a bin step falls inside the cell
         // | 0x40 when the cell reaches below the interface distance (src/dfire.rs:339)
         const DfireBinning b = build_dfire_binning();
