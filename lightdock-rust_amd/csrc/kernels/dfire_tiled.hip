@@ -273,7 +273,6 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
 
     TiledAtom *ligt = slices + wave * kSliceRecords;
     TiledAtom *rect = ligt + 64;
-    const int far_off = (int)(far_subtile - rect);  // in records, relative to this wave's receptor tile (negative)
     const int li = lane >> 3, lj = lane & 7;
     double acc = 0.0, pend0 = 0.0, pend1 = 0.0;
     uint32_t cnt = 0, tested = 0;
@@ -365,47 +364,63 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
                 LD_STAMP(td1 = __builtin_amdgcn_s_memtime(); t_dma += td1 - td0;)
                 if (COUNT) tested += (uint32_t)__popcll(smask);
 
-                // ---- 4. surviving subtile pairs, one ligand row (a) at a time ------------------
-                // ---- 4. surviving subtile pairs, two at a time (flat over the 8x8 mask) ----------
-                // bit k of smask = (ligand subtile k >> 3, receptor subtile k & 7).  Both blocks of
-                // an iteration are fully independent; an odd leftover is paired with itself and
-                // its second copy masked off (one straight-line body: the deferred gather
-                // retirement below needs no register copies).
+                // ---- 4. surviving subtile pairs, row by row ---------------------------------------
+                // bit k of smask = (ligand subtile k >> 3, receptor subtile k & 7).  The kernel is
+                // bound by LDS reads of the records as much as by VALU, so the blocks of one
+                // ligand subtile (a row of the mask, 3 on average) are done together: the ligand
+                // record is read once per row and stays in registers, and each trip of the inner
+                // loop takes two receptor subtiles of the row (4 instead of 8 ds_read_b128).  An
+                // odd one left over is paired with the far-away subtile (every pair misses).  One
+                // straight-line body; both blocks of a trip are independent.
                 while (smask) {
-                    const int k0 = __ffsll(smask) - 1;
-                    smask &= smask - 1;
-                    const bool two = smask != 0;
-                    const int k1 = two ? __ffsll(smask) - 1 : 0;
-                    smask &= smask - 1;  // 0 stays 0
-                    const int rsub1 = two ? (k1 & 7) * 8 : far_off;  // odd leftover: the far-away subtile, every pair misses
-                    RecLo L0lo, L1lo, R0lo, R1lo;
-                    RecHi L0hi, L1hi, R0hi, R1hi;
-                    read_record(&ligt[(k0 >> 3) * 8 + li], L0lo, L0hi);
-                    read_record(&rect[(k0 & 7) * 8 + lj], R0lo, R0hi);
-                    read_record(&ligt[(k1 >> 3) * 8 + li], L1lo, L1hi);
-                    read_record(&rect[rsub1 + lj], R1lo, R1hi);
-                    // (x1 - la[0])^2 + (y1 - la[1])^2 + (z1 - la[2])^2, src/dfire.rs:331-333 (x4)
-                    const double dx0 = R0lo.x - L0lo.x, dy0 = R0lo.y - L0lo.y, dz0 = R0hi.z - L0hi.z;
-                    const double dx1 = R1lo.x - L1lo.x, dy1 = R1lo.y - L1lo.y, dz1 = R1hi.z - L1hi.z;
-                    const double D0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
-                    const double D1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
-                    // cell -> table term; cells past the cutoff give kTiledLutMiss (no compare on D)
-                    uint32_t t0 = lut[min((unsigned)(int)D0, (unsigned)(kDfireLutCells - 1))];
-                    uint32_t t1 = lut[min((unsigned)(int)D1, (unsigned)(kDfireLutCells - 1))];
-                    const bool slow0 = (int)t0 >= (int)kTiledLutSlow, slow1 = (int)t1 >= (int)kTiledLutSlow;
-                    if (__builtin_expect(slow0 || slow1, 0)) {
-                        if (slow0) t0 = pair_slow_path(ctx, t0, D0, L0hi.slot, R0hi.slot);
-                        if (slow1) t1 = pair_slow_path(ctx, t1, D1, L1hi.slot, R1hi.slot);
+                    const int row = (__ffsll(smask) - 1) >> 3;
+                    unsigned rbits = (unsigned)(smask >> (row * 8)) & 0xffu;
+                    smask &= ~(0xffull << (row * 8));
+                    RecLo Llo;
+                    RecHi Lhi;
+                    read_record(&ligt[row * 8 + li], Llo, Lhi);
+                    while (rbits) {
+                        const int j0 = __ffs(rbits) - 1;
+                        rbits &= rbits - 1;
+                        const bool two = rbits != 0;
+                        const int j1 = two ? __ffs(rbits) - 1 : 0;
+                        rbits &= rbits - 1;  // 0 stays 0
+                        RecLo R0lo;
+                        RecHi R0hi;
+                        read_record(&rect[j0 * 8 + lj], R0lo, R0hi);
+                        uint32_t t1 = kTiledLutMiss, off1 = 0;
+                        double D1 = 0.0;
+                        int32_t rslot1 = -1;
+                        if (two) {  // wave-uniform: an odd block left over in its row goes alone
+                            RecLo R1lo;
+                            RecHi R1hi;
+                            read_record(&rect[j1 * 8 + lj], R1lo, R1hi);
+                            const double dx1 = R1lo.x - Llo.x, dy1 = R1lo.y - Llo.y, dz1 = R1hi.z - Lhi.z;
+                            D1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
+                            t1 = lut[min((unsigned)(int)D1, (unsigned)(kDfireLutCells - 1))];
+                            off1 = Lhi.tindex + R1hi.tindex;
+                            rslot1 = R1hi.slot;
+                        }
+                        // (x1 - la[0])^2 + (y1 - la[1])^2 + (z1 - la[2])^2, src/dfire.rs:331-333 (x4)
+                        const double dx0 = R0lo.x - Llo.x, dy0 = R0lo.y - Llo.y, dz0 = R0hi.z - Lhi.z;
+                        const double D0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
+                        // cell -> table term; cells past the cutoff give kTiledLutMiss (no compare on D)
+                        uint32_t t0 = lut[min((unsigned)(int)D0, (unsigned)(kDfireLutCells - 1))];
+                        const bool slow0 = (int)t0 >= (int)kTiledLutSlow, slow1 = (int)t1 >= (int)kTiledLutSlow;
+                        if (__builtin_expect(slow0 || slow1, 0)) {
+                            if (slow0) t0 = pair_slow_path(ctx, t0, D0, Lhi.slot, R0hi.slot);
+                            if (slow1) t1 = pair_slow_path(ctx, t1, D1, Lhi.slot, rslot1);
+                        }
+                        // retire the previous trip's gathers only now, so their L2 latency hides
+                        // behind this trip's LDS reads and arithmetic; the asm pins the order "add
+                        // the old value, then issue the new load into the same register"
+                        acc += pend0;
+                        acc += pend1;
+                        asm volatile("" : "+v"(acc) : : "memory");
+                        pend0 = table_entry(table, Lhi.tindex + R0hi.tindex + t0);  // src/dfire.rs:338, re-laid out
+                        pend1 = table_entry(table, off1 + t1);
+                        if (COUNT) cnt += (t0 < kTiledLutSlow ? 1u : 0u) + (t1 < kTiledLutSlow ? 1u : 0u);
                     }
-                    // retire the previous iteration's gathers only now, so their L2 latency hides
-                    // behind this iteration's LDS reads and arithmetic; the asm pins the order
-                    // "add the old value, then issue the new load into the same register"
-                    acc += pend0;
-                    acc += pend1;
-                    asm volatile("" : "+v"(acc) : : "memory");
-                    pend0 = table_entry(table, L0hi.tindex + R0hi.tindex + t0);  // src/dfire.rs:338, re-laid out
-                    pend1 = table_entry(table, L1hi.tindex + R1hi.tindex + t1);
-                    if (COUNT) cnt += (t0 < kTiledLutSlow ? 1u : 0u) + (t1 < kTiledLutSlow ? 1u : 0u);
                 }
                 LD_STAMP(t_loop += __builtin_amdgcn_s_memtime() - td1; t_n++;)
             }
