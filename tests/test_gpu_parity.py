@@ -405,6 +405,65 @@ def test_tiny_molecules_and_cutoff_corners(pkg, orc, table, tmp_path):
         assert got[2] == 4.7
 
 
+_RES_ATOMS = {"ALA": ["N", "CA", "C", "O", "CB"], "GLY": ["N", "CA", "C", "O"], "SER": ["N", "CA", "C", "O", "CB", "OG"],
+              "LEU": ["N", "CA", "C", "O", "CB", "CG", "CD1", "CD2"], "LYS": ["N", "CA", "C", "O", "CB", "CG", "CD", "CE", "NZ"],
+              "ASP": ["N", "CA", "C", "O", "CB", "CG", "OD1", "OD2"], "PHE": ["N", "CA", "C", "O", "CB", "CG", "CD1", "CD2", "CE1", "CE2", "CZ"]}
+
+
+def _random_molecule(rng, n_atoms, box, chain, with_beads=0):
+    """n_atoms atoms of random residues at uniform positions in a cube (dense: many pairs in every
+    distance bin, atoms of one residue far apart, i.e. loose subtile boxes); `with_beads` membrane
+    beads on top."""
+    atoms, seq = [], 1
+    names = sorted(_RES_ATOMS)
+    while len(atoms) < n_atoms:
+        res = names[int(rng.integers(len(names)))]
+        for a in _RES_ATOMS[res]:
+            if len(atoms) < n_atoms:
+                x, y, z = np.round(rng.uniform(-box / 2, box / 2, 3), 3)
+                atoms.append((a, res, chain, seq, x, y, z))
+        seq += 1
+    for _ in range(with_beads):
+        x, y, z = np.round(rng.uniform(-box / 2, box / 2, 3), 3)
+        atoms.append(("BJ", "MMB", "M", seq, x, y, z))
+        seq += 1
+    return atoms
+
+
+@pytest.mark.parametrize("n_rec,n_lig", [(1, 1), (9, 7), (64, 8), (65, 63), (200, 130), (513, 65), (1100, 300)])
+def test_random_molecules_match_oracle(pkg, orc, table, tmp_path, n_rec, n_lig):
+    """Seeded random molecules around the tile / subtile / ballot size boundaries (1, 8, 64 atoms,
+    one more, one less), random poses incl. overlapping ones, with restraints and membrane beads:
+    DFIRE on both kernels, and the all-pairs DNA kernel on the same geometry is covered by the
+    fixtures.  Energies against the oracle at 1e-11 of the summed magnitude."""
+    rng = np.random.default_rng(1000 * n_rec + n_lig)
+    rec, lig = str(tmp_path / "rec.pdb"), str(tmp_path / "lig.pdb")
+    rec_atoms = _random_molecule(rng, n_rec, 28.0, "A", with_beads=3 if n_rec >= 64 else 0)
+    lig_atoms = _random_molecule(rng, n_lig, 18.0, "B")
+    _write_pdb(rec, rec_atoms)
+    _write_pdb(lig, lig_atoms)
+    rec_active = ["A.%s.%d" % (rec_atoms[0][1], rec_atoms[0][3])]
+    lig_active = ["B.%s.%d" % (lig_atoms[-1][1], lig_atoms[-1][3])]
+    poses = np.zeros((24, 7))
+    poses[:, :3] = rng.uniform(-22, 22, (24, 3))
+    poses[:4, :3] = rng.uniform(-2, 2, (4, 3))                 # overlapping: clashes, interface flags
+    q = rng.normal(size=(24, 4))
+    poses[:, 3:] = q / np.linalg.norm(q, axis=1, keepdims=True) * rng.uniform(0.5, 2.0, (24, 1))   # non-unit too
+    cpu = orc.Scorer("dfire", rec, lig, rec_active=rec_active, lig_active=lig_active, potential=table)
+    want = cpu.energy_rows(poses)
+    scale = np.maximum(np.abs(want), 1.0)
+    for env in ({}, {"LIGHTDOCK_DFIRE_KERNEL": "allpairs"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            hip = pkg.Scorer.from_pdb("dfire", rec, lig, rec_active=rec_active, lig_active=lig_active, potential=table)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        got = hip.energy_batch(poses)
+        assert np.max(np.abs(got - want) / scale) < 1e-11, (env, n_rec, n_lig)
+
+
 def test_gso_odd_sizes(pkg, scorers, orc):
     """1 glowworm (never has a neighbour), 3 glowworms, and more glowworms than threads in a
     workgroup (1030 > 1024): same as the oracle."""
