@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 L=lightdock-rust_amd/lib
 cp $L/liblightdock_hip.so /tmp/keep.so
-for round in 1 2 3; do
+for round in 1 2; do
   for v in $L/variants/*.so; do
     cp $v $L/liblightdock_hip.so
     r=$(timeout 90 python bench.py --cpu-seconds 0 "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.0f evals/s kernel %.3f ms' % (d['value'], d['roofline']['kernel_ms']))" 2>&1 | tail -1)
