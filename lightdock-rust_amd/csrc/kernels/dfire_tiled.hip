@@ -10,14 +10,16 @@
 //      src/dfire.rs:282-302), parks the 32-byte records in its private 2 KiB LDS slice and
 //      builds 8 subtile boxes (8 atoms each) + the tile box with xor-shuffle butterflies.
 //   2. 64 lanes test the tile box against 64 receptor tile boxes per ballot.
-//   3. Every surviving receptor tile is copied HBM/L2 -> LDS (64 lanes x 32 B, coalesced; the
-//      next tile's loads are issued before the current tile is processed), and 64 lanes test
-//      the 8 x 8 subtile-box pairs in one ballot.
-//   4. Every surviving subtile pair is one wave iteration of 64 distinct atom pairs: lane
-//      (i, j) takes ligand atom i and receptor atom j of the pair, both from LDS, and runs the
-//      reference's pair body: f64 d2 in the reference's operation order, cutoff, distance bin
-//      (exact LUT), potential[type_i][type_j][bin] gather, interface flags.  Two subtile pairs
-//      of one ligand row are in flight at a time so their LDS/L2 latencies overlap.
+//   3. Every surviving receptor tile is copied L2 -> LDS by LDS-DMA (64 lanes x 2 x 16 B, no
+//      VGPRs), and while the copy is in flight 64 lanes test the 8 x 8 subtile-box pairs in
+//      one ballot.
+//   4. The surviving subtile pairs are done row by row (row = one ligand subtile): the ligand
+//      record is read once per row, each trip of the inner loop takes two receptor subtiles.
+//      A block is 64 distinct atom pairs: lane (i, j) takes ligand atom i and receptor atom j
+//      and runs the reference's pair body: f64 d2 in the reference's operation order, distance
+//      bin through an exact cell LUT (which also encodes the cutoff), gather of
+//      potential[type_i][type_j][bin] from a table re-laid out in 128-byte patches, interface
+//      flags on a rare slow path.  The two gathers of a trip are retired one trip later.
 //   5. wave64 shuffle reduction; one partial per (pose, workgroup).
 // The receptor image (records + boxes) is static in HBM/L2 and shared by all poses; with
 // receptor ANM (src/dfire.rs:304-320) dfire_prepare_receptor writes one image per pose first.
@@ -30,7 +32,7 @@
 #include <cmath>
 
 #ifdef LD_TILED_STAMPS
-// diagnostic build (make STAMPS=1): s_memtime stamps summed over all waves, read by tools/stamps_experiment.py
+// diagnostic build (tools/build_stamps_variant.sh): s_memtime stamps summed over all waves, read by tools/stamps_experiment.py
 __device__ unsigned long long g_ld_stamps[8];
 extern "C" int ld_debug_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ld_stamps), 64); }
 #define LD_STAMP(...) __VA_ARGS__
@@ -212,8 +214,8 @@ __device__ __forceinline__ double table_entry(__amdgpu_buffer_rsrc_t table, uint
     return __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
 }
 
-// MAXT/MINW = launch bounds.  Capping registers at 64 (8 waves per SIMD) was measured SLOWER on
-// MI355X (spills + no gain from occupancy: the kernel is bound by L2 gather requests), so MINW = 1.
+// MAXT/MINW = launch bounds.  The 256-thread instantiation needs 50 VGPRs without any cap; 8
+// workgroups per CU are set by its 20 448 bytes of LDS.
 template <bool COUNT, int MAXT, int MINW>
 __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunch T) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
