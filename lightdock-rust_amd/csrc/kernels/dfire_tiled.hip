@@ -215,7 +215,7 @@ __device__ __forceinline__ double table_entry(__amdgpu_buffer_rsrc_t table, uint
 }
 
 // MAXT/MINW = launch bounds.  The 256-thread instantiation needs 50 VGPRs without any cap; 8
-// workgroups per CU are set by its 20 448 bytes of LDS.
+// workgroups per CU are set by its 20 192 bytes of LDS.
 template <bool COUNT, int MAXT, int MINW>
 __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunch T) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -224,10 +224,8 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
     size_t off = kDfireLutCells * sizeof(uint32_t);
     double *bin_step = reinterpret_cast<double *>(smem + off);
     off += kDfireSteps * sizeof(double);
-    TiledAtom *far_subtile = reinterpret_cast<TiledAtom *>(smem + off);  // 8 records no pair can reach
-    off += 8 * sizeof(TiledAtom);
     TiledAtom *slices = reinterpret_cast<TiledAtom *>(smem + off);  // per wave: kSliceRecords records
-    // 3616 + 192 + 256 + 4 x 4096 = 20 448 bytes for 4 waves: 8 workgroups (32 waves) per CU.  The
+    // 3616 + 192 + 4 x 4096 = 20 192 bytes for 4 waves: 8 workgroups (32 waves) per CU.  The
     // per-wave results of the final reduction reuse the first 16 bytes of each wave's own slice.
 
     LD_STAMP(const unsigned long long ts0 = __builtin_amdgcn_s_memtime(); unsigned long long t_setup = 0, t_dma = 0, t_loop = 0, t_n = 0; unsigned long long td0 = 0, td1 = 0;)
@@ -262,15 +260,6 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
     for (int i = tid; i < kDfireLutCells / 4; i += blockDim.x)
         reinterpret_cast<uint4 *>(lut)[i] = reinterpret_cast<const uint4 *>(T.lut)[i];
     if (tid < kDfireSteps) bin_step[tid] = 4.0 * T.bin_step[tid];  // scaled coordinates
-    if (tid < 8) {  // partner of an odd leftover block: every pair misses
-        TiledAtom far;
-        far.x = -1.0e30;
-        far.y = 0.0;
-        far.z = 0.0;
-        far.tindex = 0;
-        far.slot = -1;
-        far_subtile[tid] = far;
-    }
     __syncthreads();
 
     TiledAtom *ligt = slices + wave * kSliceRecords;
@@ -477,7 +466,7 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
 }  // namespace
 
 size_t tiled_kernel_lds_bytes(const TiledLaunch &t) {
-    size_t b = kDfireLutCells * sizeof(uint32_t) + kDfireSteps * sizeof(double) + 8 * sizeof(TiledAtom);
+    size_t b = kDfireLutCells * sizeof(uint32_t) + kDfireSteps * sizeof(double);
     b += (size_t)t.waves * kSliceRecords * sizeof(TiledAtom);
     return b;
 }
