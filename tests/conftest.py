@@ -59,6 +59,8 @@ CASES = {
                  anm_rec=10, anm_lig=10),
     "2uuy": dict(method="dfire", rec="lightdock_2UUY_rec.pdb", lig="lightdock_2UUY_lig.pdb", use_anm=True, anm_rec=10,
                  anm_lig=10),
+    "ab_icode": dict(method="dfire", rec="lightdock_receptor.pdb", lig="lightdock_ligand.pdb",
+                     rec_active=["H.ASP.52A", "H.LEU.82C"], use_anm=True, anm_rec=10, anm_lig=10),
     "1azp": dict(method="dna", rec="lightdock_protein.pdb", lig="lightdock_dna.pdb",
                  rec_active=["A.TRP.24", "A.VAL.26", "A.ARG.42"], lig_active=["B.DT.13"], use_anm=True, anm_rec=10,
                  anm_lig=10),

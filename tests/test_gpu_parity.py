@@ -47,7 +47,7 @@ def test_native_library_is_loaded(pkg):
     assert lib.ld_init(0) == 0
 
 
-@pytest.mark.parametrize("name,n", [("1ppe", 200), ("1k4c", 200), ("2uuy", 120), ("1azp", 200)])
+@pytest.mark.parametrize("name,n", [("1ppe", 200), ("1k4c", 200), ("2uuy", 120), ("ab_icode", 60), ("1azp", 200)])
 def test_pose_energies_match_oracle(scorers, orc, name, n):
     """K1 over the reference's starting poses: DFIRE (+restraint, +membrane, +ANM) and DNA+ANM."""
     hip, cpu = scorers(name)

@@ -57,7 +57,7 @@ def test_header_is_plain_c_and_a_c_program_links(pkg, orc, tmp_path):
     assert "gfx950" in version
 
 
-@pytest.mark.parametrize("name", ["1ppe", "1k4c", "2uuy", "1azp"])
+@pytest.mark.parametrize("name", ["1ppe", "1k4c", "2uuy", "ab_icode", "1azp"])
 def test_host_model_builder_matches_oracle(pkg, orc, table, name):
     c, d, rec, lig = case_paths(name)
     from conftest import case_kwargs
@@ -73,6 +73,25 @@ def test_host_model_builder_matches_oracle(pkg, orc, table, name):
         assert np.array_equal(m["membrane"], w["membrane"])
         assert np.array_equal(m["restraint_offsets"], w["restraint_offsets"])
         assert np.array_equal(m["restraint_atoms"], w["restraint_atoms"])
+
+
+def test_insertion_code_restraints_ab_icode(pkg, orc):
+    """Restraint ids carry the insertion code without a separator (src/dfire.rs:139-142):
+    "H.ASP.52A" and "H.LEU.82C" of example/ab_icode must each find their residue's atoms, and
+    not those of H.52 / H.82 (same serial, no or another insertion code)."""
+    c, d, rec, lig = case_paths("ab_icode")
+    m = pkg.model_from_pdb("dfire", rec, active=c["rec_active"])
+    offs, atoms = m["restraint_offsets"], m["restraint_atoms"]
+    assert len(offs) == 3 and offs[1] > 0 and offs[2] > offs[1]          # two groups, both non-empty
+    lines = [l for l in open(rec) if l.startswith(("ATOM", "HETATM"))]
+    want = {"52A": ("ASP", 8), "82C": ("LEU", 8)}
+    groups = [set(atoms[offs[g]:offs[g + 1]].tolist()) for g in range(2)]
+    for key, (resname, n_atoms) in want.items():
+        idx = {i for i, l in enumerate(lines) if l[21] == "H" and l[22:27].strip() == key}
+        assert len(idx) == n_atoms and all(lines[i][17:20] == resname for i in idx)
+        assert idx in groups
+    none = pkg.model_from_pdb("dfire", rec, active=["H.ASP.52", "H.LEU.82"])   # without the code: other residues or nothing
+    assert set(none["restraint_atoms"].tolist()).isdisjoint(set(atoms.tolist()))
 
 
 def test_pdb_walk_order_groups_like_pdbtbx(pkg, orc, table, tmp_path):

@@ -119,6 +119,15 @@ def test_real_dcparams_goldens(orc, real_dcparams):
     d = os.path.join(GOLDEN, "unit", "2oob")
     s = orc.Scorer("dfire", os.path.join(d, "2oob_receptor.pdb"), os.path.join(d, "2oob_ligand.pdb"), potential=t)
     assert s.energy([0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]) == 16.7540569503498
+    # step-1 files of the DFIRE examples: the "Scoring" column is the energy of the initial poses
+    # (src/lib.rs:51, src/swarm.rs:128-167), printed with 8 decimals
+    from conftest import case_kwargs, case_positions, parse_gso
+    for name in ("1ppe", "1k4c", "2uuy", "ab_icode"):
+        method, rec, lig, kw = case_kwargs(name, orc, t)
+        poses = case_positions(name, orc)
+        want = parse_gso(os.path.join(GOLDEN, name, "swarm_0", "gso_1.out"))[4]
+        got = orc.Scorer(method, rec, lig, **kw).energy_rows(poses[:40])
+        assert np.all(np.abs(got - want[:40]) <= 1.01e-8 + 1e-9 * np.abs(want[:40])), name
 
 
 def test_pydock_known_answer_and_generic_fallback(orc, tmp_path):
