@@ -464,6 +464,28 @@ def test_random_molecules_match_oracle(pkg, orc, table, tmp_path, n_rec, n_lig):
         assert np.max(np.abs(got - want) / scale) < 1e-11, (env, n_rec, n_lig)
 
 
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("name", ["1ppe", "1azp"])
+def test_degenerate_poses_neither_hang_nor_poison_the_batch(scorers, orc, name):
+    """NaN / infinite translations and a zero quaternion (rotate divides by |q|^2, src/qt.rs:48-50)
+    give garbage energies in the reference too; here they must not hang a kernel, and the valid
+    poses of the same batch must keep their exact energies."""
+    hip, cpu = scorers(name)
+    poses = case_positions(name, orc)[:12].copy()
+    good = hip.energy_batch(poses)
+    bad = poses.copy()
+    bad[1, 0] = np.nan
+    bad[3, :3] = [np.inf, -np.inf, 1e308]
+    bad[5, 3:7] = 0.0
+    bad[7, :3] = 1e15
+    got = hip.energy_batch(bad)
+    keep = [0, 2, 4, 6, 8, 9, 10, 11]
+    assert np.array_equal(got[keep], good[keep])
+    far = cpu.energy_row(bad[7])
+    assert got[7] == far                                   # nothing in range: the same constant as the CPU path
+    assert np.array_equal(hip.energy_batch(poses), good)   # and the scorer is still usable
+
+
 def test_gso_odd_sizes(pkg, scorers, orc):
     """1 glowworm (never has a neighbour), 3 glowworms, and more glowworms than threads in a
     workgroup (1030 > 1024): same as the oracle."""
