@@ -52,6 +52,8 @@ def main(argv=None):
     pkg = ge.package()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("LIGHTDOCK_DEVICE") is not None:      # e.g. several ranks on one GPU for a dry run
+        local = int(os.environ["LIGHTDOCK_DEVICE"])
     pkg.init(local)
     setup = json.load(open(args.setup))
     sim = os.path.dirname(os.path.abspath(args.setup))

@@ -636,6 +636,22 @@ def test_multi_swarm_launcher(pkg, tmp_path):
             b = open(single / ("swarm_%d" % s) / ("gso_%d.out" % step)).read()
             assert a == b
         assert not os.path.exists(run / ("swarm_%d" % s) / "gso_12.out")
+    # the same three swarms sharded over two ranks (one process per GPU under torchrun; both ranks
+    # share device 0 here): rank 0 takes swarms 0 and 2, rank 1 swarm 1; same files
+    run2 = tmp_path / "run2"
+    run2.mkdir()
+    for f in ("rec_nm.npy", "lig_nm.npy"):
+        shutil.copy(os.path.join(src, f), run2)
+    env = dict(os.environ, LIGHTDOCK_DEVICE="0")
+    r = subprocess.run([os.sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29533", launcher, os.path.join(src, "setup.json"), "12", "dna",
+                        "--swarms", "0-2", "--init-dir", str(init)], cwd=run2, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rank 0/2: 2 swarms" in r.stdout and "rank 1/2: 1 swarms" in r.stdout
+    for s in range(3):
+        for step in (1, 10):
+            name = os.path.join("swarm_%d" % s, "gso_%d.out" % step)
+            assert open(run2 / name).read() == open(run / name).read()
 
 
 def test_block_count_diagnostics(pkg, scorers, orc):
