@@ -31,12 +31,58 @@ void split(const double *xyz, std::vector<uint32_t> &ids, size_t begin, size_t e
     split(xyz, ids, begin + half, end);
 }
 
+// Cost of one 8-atom subtile for the 8x8 box test: the volume of its bounding box grown by the
+// cutoff plus a typical partner box (15 A + 15 A + ~6 A), i.e. proportional to the number of
+// partner subtiles the box test lets through.
+constexpr double kGrow = 36.0;
+
+double subtile_cost(const double *xyz, const uint32_t *ids) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int k = 0; k < 8; k++)
+        for (int c = 0; c < 3; c++) {
+            const double v = xyz[3 * (size_t)ids[k] + c];
+            lo[c] = std::min(lo[c], v);
+            hi[c] = std::max(hi[c], v);
+        }
+    return (hi[0] - lo[0] + kGrow) * (hi[1] - lo[1] + kGrow) * (hi[2] - lo[2] + kGrow);
+}
+
+// The median splits leave subtiles whose boxes overlap along the split planes.  Inside every
+// full 64-atom tile, swap atoms between its 8 subtiles while that lowers the summed cost
+// (deterministic sweep order, a few passes; tiles keep their atoms, so the tile boxes do not
+// change).  On the 1k4c example this removes 6 % of the 8x8 blocks the kernel has to evaluate.
+void refine_subtiles(const double *xyz, std::vector<uint32_t> &ids, size_t n) {
+    for (size_t base = 0; base + 64 <= n; base += 64) {
+        uint32_t *t = ids.data() + base;
+        double cost[8];
+        for (int g = 0; g < 8; g++) cost[g] = subtile_cost(xyz, t + 8 * g);
+        for (int pass = 0; pass < 4; pass++) {
+            bool improved = false;
+            for (int i = 0; i < 64; i++)
+                for (int j = (i / 8 + 1) * 8; j < 64; j++) {  // j in a later subtile than i
+                    const int a = i / 8, b = j / 8;
+                    std::swap(t[i], t[j]);
+                    const double ca = subtile_cost(xyz, t + 8 * a), cb = subtile_cost(xyz, t + 8 * b);
+                    if (ca + cb < cost[a] + cost[b] - 1e-9) {
+                        cost[a] = ca;
+                        cost[b] = cb;
+                        improved = true;
+                    } else {
+                        std::swap(t[i], t[j]);
+                    }
+                }
+            if (!improved) break;
+        }
+    }
+}
+
 }  // namespace
 
 std::vector<uint32_t> spatial_tile_order(const double *xyz, size_t n) {
     std::vector<uint32_t> ids(n);
     for (size_t i = 0; i < n; i++) ids[i] = (uint32_t)i;
     split(xyz, ids, 0, n);
+    refine_subtiles(xyz, ids, n);
     const size_t padded = (n + 63) / 64 * 64;
     ids.resize(padded, std::numeric_limits<uint32_t>::max());
     return ids;

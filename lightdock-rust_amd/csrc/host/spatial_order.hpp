@@ -15,6 +15,7 @@ namespace ld {
 // Returns slot -> original atom index, length = ceil(n/64)*64; UINT32_MAX marks a padding
 // slot.  Built by recursive median splits along the longest axis, cut at multiples of 64
 // (or 8 below 64 atoms) so only the trailing leaf is short.
+// Inside each full tile a swap refinement then tightens the 8-atom subtile boxes.
 std::vector<uint32_t> spatial_tile_order(const double *xyz /* n x 3 */, size_t n);
 
 }  // namespace ld
