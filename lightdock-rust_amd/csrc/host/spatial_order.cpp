@@ -93,4 +93,46 @@ std::vector<uint32_t> spatial_tile_order(const double *xyz, size_t n) {
     return ids;
 }
 
+std::vector<uint32_t> pair_types_for_patches(const double *xyz, const uint32_t *types, const std::vector<uint32_t> &order,
+                                             uint32_t n_types) {
+    const uint32_t kPad = std::numeric_limits<uint32_t>::max();
+    std::vector<double> w((size_t)n_types * n_types, 0.0);
+    for (size_t base = 0; base + 8 <= order.size(); base += 8)
+        for (int i = 0; i < 8; i++)
+            for (int j = i + 1; j < 8; j++) {
+                const uint32_t a = order[base + i], b = order[base + j];
+                if (a == kPad || b == kPad) continue;
+                const uint32_t ta = types[a], tb = types[b];
+                if (ta == tb || ta >= n_types || tb >= n_types) continue;
+                double d2 = 0.0;
+                for (int c = 0; c < 3; c++) {
+                    const double d = xyz[3 * (size_t)a + c] - xyz[3 * (size_t)b + c];
+                    d2 += d * d;
+                }
+                const double v = 1.0 / (1.0 + d2);
+                w[(size_t)ta * n_types + tb] += v;
+                w[(size_t)tb * n_types + ta] += v;
+            }
+    struct Edge {
+        double weight;
+        uint32_t a, b;
+    };
+    std::vector<Edge> edges;
+    for (uint32_t a = 0; a < n_types; a++)
+        for (uint32_t b = a + 1; b < n_types; b++)
+            if (w[(size_t)a * n_types + b] > 0.0) edges.push_back({w[(size_t)a * n_types + b], a, b});
+    std::stable_sort(edges.begin(), edges.end(), [](const Edge &x, const Edge &y) { return x.weight > y.weight; });
+    std::vector<uint32_t> perm(n_types, kPad);
+    uint32_t next = 0;
+    for (const Edge &e : edges)
+        if (perm[e.a] == kPad && perm[e.b] == kPad) {
+            perm[e.a] = next;
+            perm[e.b] = next + 1;
+            next += 2;
+        }
+    for (uint32_t a = 0; a < n_types; a++)
+        if (perm[a] == kPad) perm[a] = next++;
+    return perm;
+}
+
 }  // namespace ld

@@ -18,4 +18,12 @@ namespace ld {
 // Inside each full tile a swap refinement then tightens the 8-atom subtile boxes.
 std::vector<uint32_t> spatial_tile_order(const double *xyz /* n x 3 */, size_t n);
 
+// Renumbering of the DFIRE atom types (0..168) of one molecule for the tiled kernel's table
+// layout, which keeps the potential of two consecutive type numbers in the same 128-byte patch
+// (kernels/dfire_tiled.hpp): types that sit close together inside the subtiles of `order` (bonded
+// atoms of one residue, mostly) become the pairs (2k, 2k+1).  Greedy matching on a closeness-
+// weighted co-occurrence count; deterministic.  Returns old type -> new type, a bijection.
+std::vector<uint32_t> pair_types_for_patches(const double *xyz, const uint32_t *types, const std::vector<uint32_t> &order,
+                                             uint32_t n_types);
+
 }  // namespace ld

@@ -311,6 +311,9 @@ void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, Tiled
     std::vector<uint32_t> t(np, 0);
     std::vector<int32_t> slot(np, -1);
     const std::vector<int32_t> &hslot = is_receptor ? host_slot_rec_ : host_slot_lig_;
+    // type numbers as the patch layout of the potential wants them (bonded atoms paired up)
+    std::vector<uint32_t> &perm = is_receptor ? type_perm_rec_ : type_perm_lig_;
+    perm = pair_types_for_patches(m.coordinates, m.dfire_types, order, 169);
     for (size_t i = 0; i < np; i++) {
         const uint32_t a = order[i];
         if (a == kPad) {
@@ -320,7 +323,7 @@ void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, Tiled
         x[i] = m.coordinates[3 * (size_t)a];
         y[i] = m.coordinates[3 * (size_t)a + 1];
         z[i] = m.coordinates[3 * (size_t)a + 2];
-        t[i] = is_receptor ? tiled_rec_term(m.dfire_types[a]) : tiled_lig_term(m.dfire_types[a]);
+        t[i] = is_receptor ? tiled_rec_term(perm[m.dfire_types[a]]) : tiled_lig_term(perm[m.dfire_types[a]]);
         slot[i] = hslot[a];
     }
     out.n_real = (int)n;
@@ -368,7 +371,8 @@ void Scorer::build_tiled(const ld_scorer_desc &desc) {
         for (uint32_t l = 0; l < 168; l++)
             for (uint32_t b = 0; b < kTiledTableBins; b++)
                 for (uint32_t r = 0; r < 168; r++)
-                    t2[(tiled_lig_term(l) + tiled_rec_term(r) + tiled_bin_term(b)) / 8] = desc.potential[(size_t)r * kDfireRowStride + l * 20 + b];
+                    t2[(tiled_lig_term(type_perm_lig_[l]) + tiled_rec_term(type_perm_rec_[r]) + tiled_bin_term(b)) / 8] =
+                        desc.potential[(size_t)r * kDfireRowStride + l * 20 + b];
         tiled_.table = arena_.upload(t2);
     }
     tiled_.bin_step = pair_.bin_step;

@@ -126,6 +126,7 @@ class Scorer {
     TiledSoA tiled_rec_soa_;          // receptor in tile order (input of dfire_prepare_receptor)
     bool rec_anm_per_pose_ = false;   // receptor ANM: one receptor image per pose per launch
     DeviceBuffer ws_rec_atoms_, ws_rec_sub_, ws_rec_tile_;
+    std::vector<uint32_t> type_perm_rec_, type_perm_lig_;  // DFIRE type -> number used by the tiled kernel's table layout
     std::vector<int32_t> host_slot_rec_, host_slot_lig_;  // per original atom, as uploaded to the all-pairs path
     HostMolecule host_rec_, host_lig_;
     DeviceBuffer ws_partial_, ws_flags_, ws_counts_, ws_tested_, ws_poses_, ws_energies_;
