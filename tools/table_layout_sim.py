@@ -34,30 +34,52 @@ def bin_of(d2):
     b = (lut[cell] & 31).astype(np.int64)
     b = b + (d2 >= steps[np.minimum(b+1, 20)])   # exact step
     return b
-layouts = {}
-for a, b, c in [(1,1,16),(1,16,1),(1,8,2),(1,4,4),(2,8,1),(4,4,1),(2,4,2),(4,2,2),(2,2,4),(4,1,4),(8,1,2),(1,8,1),(2,2,2),(1,1,8),(2,4,4),(4,4,4)]:
-    layouts[(a,b,c)] = 0
+def pair_types(c, t, v):
+    """the library's type renumbering (host/spatial_order.cpp: pair_types_for_patches), restated"""
+    n = len(c) // 8
+    C = np.zeros((169, 169))
+    cc = c.reshape(n, 8, 3); tt = t.reshape(n, 8); vv = v.reshape(n, 8)
+    for s_ in range(n):
+        for i in range(8):
+            for j in range(i + 1, 8):
+                if vv[s_, i] and vv[s_, j] and tt[s_, i] != tt[s_, j]:
+                    w = 1.0 / (1.0 + ((cc[s_, i] - cc[s_, j]) ** 2).sum())
+                    C[tt[s_, i], tt[s_, j]] += w; C[tt[s_, j], tt[s_, i]] += w
+    perm = -np.ones(169, dtype=np.int64); nxt = 0
+    edges = sorted(((-C[a, b], a, b) for a in range(169) for b in range(a + 1, 169) if C[a, b] > 0))
+    for w, a, b in edges:
+        if perm[a] < 0 and perm[b] < 0:
+            perm[a], perm[b] = nxt, nxt + 1; nxt += 2
+    for a in range(169):
+        if perm[a] < 0:
+            perm[a] = nxt; nxt += 1
+    return perm
+numberings = {"reference type numbers": (lt, rt), "types paired per molecule (library)": (pair_types(lc0, lt, lv)[lt], pair_types(rc, rt, rv)[rt])}
+shapes = [(1,1,16),(1,16,1),(1,8,2),(1,4,4),(2,8,1),(4,4,1),(2,4,2),(4,2,2),(2,2,4),(4,1,4),(8,1,2),(1,8,1),(2,2,2),(1,1,8),(2,4,4),(4,4,4)]
+counts = {(k, sh): 0 for k in numberings for sh in shapes}
 hits_total = 0; blocks_total = 0
-rng = np.random.default_rng(0)
 for p in pos[::25]:
     R = rotmat(p[3:7]); l = lc0 @ R.T + p[:3]; l[~lv] = -1e9
     llo, lhi = boxes(l, lv, 8)
     gap = np.maximum(0, np.maximum(llo[:, None, :]-rhi[None, :, :], rlo[None, :, :]-lhi[:, None, :]))
     act = np.argwhere((gap**2).sum(-1) <= 225.0)
     blocks_total += len(act)
-    L = l.reshape(-1, 8, 3); Rr = rc.reshape(-1, 8, 3); LT = lt.reshape(-1, 8); RT = rt.reshape(-1, 8)
+    L = l.reshape(-1, 8, 3); Rr = rc.reshape(-1, 8, 3)
     for chunk in np.array_split(act, max(1, len(act)//2000)):
         ls, rs = chunk[:, 0], chunk[:, 1]
-        d = L[ls][:, :, None, :] - Rr[rs][:, None, :, :]
-        d2 = (d*d).sum(-1)                                    # (nb, 8, 8)
+        d2 = ((L[ls][:, :, None, :] - Rr[rs][:, None, :, :])**2).sum(-1)
         hit = d2 <= 225.0
         bins = bin_of(np.where(hit, d2, 0.0))
-        lt_ = np.broadcast_to(LT[ls][:, :, None], d2.shape); rt_ = np.broadcast_to(RT[rs][:, None, :], d2.shape)
         hits_total += hit.sum()
         blk = np.broadcast_to(np.arange(len(chunk))[:, None, None], d2.shape)
-        for (a, b, c) in layouts:
-            key = ((blk*200 + lt_//a)*200 + rt_//b)*32 + bins//c
-            layouts[(a, b, c)] += len(np.unique(key[hit]))
-print(name, "blocks/pose %.0f hits/pose %.0f hits/block %.1f" % (blocks_total/len(pos[::25]), hits_total/len(pos[::25]), hits_total/blocks_total))
-for k, v in sorted(layouts.items(), key=lambda kv: (kv[0][0]*kv[0][1]*kv[0][2], kv[1])):
-    print("  sector = %d lig x %d rec x %d bins (%3d B): %.3f sectors/hit" % (k[0], k[1], k[2], 8*k[0]*k[1]*k[2], v/hits_total))
+        for k, (ltm, rtm) in numberings.items():
+            lt_ = np.broadcast_to(ltm.reshape(-1, 8)[ls][:, :, None], d2.shape); rt_ = np.broadcast_to(rtm.reshape(-1, 8)[rs][:, None, :], d2.shape)
+            for (a, b, c) in shapes:
+                key = ((blk*200 + lt_//a)*200 + rt_//b)*32 + bins//c
+                counts[(k, (a, b, c))] += len(np.unique(key[hit]))
+n_p = len(pos[::25])
+print(name, "blocks/pose %.0f hits/pose %.0f hits/block %.1f" % (blocks_total/n_p, hits_total/n_p, hits_total/blocks_total))
+for k in numberings:
+    print(k)
+    for sh in sorted(shapes, key=lambda s_: (s_[0]*s_[1]*s_[2], counts[(k, s_)])):
+        print("  patch = %d lig x %d rec x %d bins (%3d B): %.3f lines/hit" % (sh[0], sh[1], sh[2], 8*sh[0]*sh[1]*sh[2], counts[(k, sh)]/hits_total))
