@@ -127,6 +127,13 @@ int ld_dfire_bin_lut(uint8_t *lut_out /* 901 */, double *steps_out /* 21 */, dou
  * slots ("tile") are spatially compact; padding only at the tail.  The energy is a plain sum over
  * pairs (src/dfire.rs:325-345), so the order is free.  Returns the padded length. */
 size_t ld_spatial_tile_order(const double *xyz /* n x 3 */, size_t n, uint32_t *order_out);
+/* The complete layout the DFIRE scorer uses for one molecule (host-side, no GPU): the order above
+ * refined so that atom types which share a 128-byte patch of the re-laid-out potential sit in the
+ * same subtile, and the renumbering of the DFIRE types (type_perm_out[type] = number in the patch
+ * layout; 2k and 2k+1 share patches).  order_out: ceil(n/64)*64 entries, type_perm_out: 169.
+ * Returns the padded length. */
+size_t ld_dfire_tile_layout(const double *xyz /* n x 3 */, const uint32_t *dfire_types /* n */, size_t n,
+                            uint32_t *order_out, uint32_t *type_perm_out);
 
 /* rand 0.7.3 StdRng::seed_from_u64 -> the 8 ChaCha20 key words the GSO kernel uses (src/lib.rs:38). */
 void ld_stdrng_key(uint64_t seed, uint32_t key_out[8]);

@@ -224,6 +224,23 @@ def spatial_tile_order(xyz):
     return out
 
 
+def dfire_tile_layout(xyz, dfire_types):
+    """(order, type_perm) the DFIRE scorer uses for one molecule: order[slot] = atom index
+    (UINT32_MAX = padding), type_perm[type] = number in the patch layout of the potential."""
+    xyz = _f64(xyz).reshape(-1, 3)
+    types = np.ascontiguousarray(dfire_types, dtype=np.uint32)
+    n = xyz.shape[0]
+    order = np.zeros((n + 63) // 64 * 64, dtype=np.uint32)
+    perm = np.zeros(169, dtype=np.uint32)
+    lib = load_library()
+    lib.ld_dfire_tile_layout.restype = C.c_size_t
+    lib.ld_dfire_tile_layout.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    got = lib.ld_dfire_tile_layout(_ptr(xyz), _ptr(types), n, _ptr(order), _ptr(perm))
+    if got != order.size:
+        raise LightdockError(-1, lib.ld_last_error().decode())
+    return order, perm
+
+
 def stdrng_key(seed):
     key = np.zeros(8, dtype=np.uint32)
     load_library().ld_stdrng_key(seed, _ptr(key))

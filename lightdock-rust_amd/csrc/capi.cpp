@@ -173,6 +173,18 @@ size_t ld_spatial_tile_order(const double *xyz, size_t n, uint32_t *order_out) {
     });
     return len;
 }
+size_t ld_dfire_tile_layout(const double *xyz, const uint32_t *dfire_types, size_t n, uint32_t *order_out,
+                            uint32_t *type_perm_out) {
+    size_t len = 0;
+    guarded([&] {
+        if ((!xyz || !dfire_types) && n) throw ld::Error(LD_ERR_INVALID, "null coordinates / types");
+        const ld::DfireTileLayout layout = ld::dfire_tile_layout(xyz, dfire_types, n);
+        if (order_out) std::memcpy(order_out, layout.order.data(), layout.order.size() * sizeof(uint32_t));
+        if (type_perm_out) std::memcpy(type_perm_out, layout.type_perm.data(), layout.type_perm.size() * sizeof(uint32_t));
+        len = layout.order.size();
+    });
+    return len;
+}
 void ld_stdrng_key(uint64_t seed, uint32_t key_out[8]) { ld::stdrng_key_from_seed(seed, key_out); }
 
 int ld_load_dcparams(const char *path, double *out) {

@@ -135,4 +135,50 @@ std::vector<uint32_t> pair_types_for_patches(const double *xyz, const uint32_t *
     return perm;
 }
 
+void refine_order_for_pairs(const double *xyz, const uint32_t *types, const std::vector<uint32_t> &perm,
+                            std::vector<uint32_t> &order, size_t n, double mu) {
+    auto cost_of = [&](const uint32_t *ids) {
+        uint32_t pt[8];
+        for (int k = 0; k < 8; k++) pt[k] = perm[types[ids[k]]];
+        int lonely = 0;
+        for (int k = 0; k < 8; k++) {
+            bool found = false;
+            for (int m = 0; m < 8; m++) found = found || pt[m] == (pt[k] ^ 1u);
+            lonely += found ? 0 : 1;
+        }
+        return subtile_cost(xyz, ids) * (1.0 + mu * lonely / 8.0);
+    };
+    for (size_t base = 0; base + 64 <= n; base += 64) {
+        uint32_t *t = order.data() + base;
+        double cost[8];
+        for (int g = 0; g < 8; g++) cost[g] = cost_of(t + 8 * g);
+        for (int pass = 0; pass < 4; pass++) {
+            bool improved = false;
+            for (int i = 0; i < 64; i++)
+                for (int j = (i / 8 + 1) * 8; j < 64; j++) {
+                    const int a = i / 8, b = j / 8;
+                    std::swap(t[i], t[j]);
+                    const double ca = cost_of(t + 8 * a), cb = cost_of(t + 8 * b);
+                    if (ca + cb < cost[a] + cost[b] - 1e-9) {
+                        cost[a] = ca;
+                        cost[b] = cb;
+                        improved = true;
+                    } else {
+                        std::swap(t[i], t[j]);
+                    }
+                }
+            if (!improved) break;
+        }
+    }
+}
+
+DfireTileLayout dfire_tile_layout(const double *xyz, const uint32_t *types, size_t n) {
+    DfireTileLayout out;
+    out.order = spatial_tile_order(xyz, n);
+    out.type_perm = pair_types_for_patches(xyz, types, out.order, 169);
+    refine_order_for_pairs(xyz, types, out.type_perm, out.order, n, 0.15);
+    out.type_perm = pair_types_for_patches(xyz, types, out.order, 169);
+    return out;
+}
+
 }  // namespace ld

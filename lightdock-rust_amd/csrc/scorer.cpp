@@ -304,7 +304,8 @@ Scorer::Scorer(const ld_scorer_desc &desc) {
 // (receptor) / +1e30 (ligand) so that no padding/padding pair can ever look close.
 void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, TiledSoA &out) {
     const size_t n = m.n_atoms;
-    const std::vector<uint32_t> order = spatial_tile_order(m.coordinates, n);
+    const DfireTileLayout layout = dfire_tile_layout(m.coordinates, m.dfire_types, n);
+    const std::vector<uint32_t> &order = layout.order;
     const size_t np = order.size();
     const uint32_t kPad = std::numeric_limits<uint32_t>::max();
     std::vector<double> x(np, is_receptor ? -1.0e30 : 1.0e30), y(np, 0.0), z(np, 0.0);
@@ -313,7 +314,7 @@ void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, Tiled
     const std::vector<int32_t> &hslot = is_receptor ? host_slot_rec_ : host_slot_lig_;
     // type numbers as the patch layout of the potential wants them (bonded atoms paired up)
     std::vector<uint32_t> &perm = is_receptor ? type_perm_rec_ : type_perm_lig_;
-    perm = pair_types_for_patches(m.coordinates, m.dfire_types, order, 169);
+    perm = layout.type_perm;
     for (size_t i = 0; i < np; i++) {
         const uint32_t a = order[i];
         if (a == kPad) {

@@ -341,3 +341,30 @@ def test_spatial_tile_order(pkg, orc, table):
         pts = np.random.default_rng(m).normal(size=(m, 3))
         o = pkg.spatial_tile_order(pts)
         assert o.size == (m + 63) // 64 * 64 and np.array_equal(np.sort(o[:m]), np.arange(m)) and np.all(o[m:] == 0xFFFFFFFF)
+
+
+def test_dfire_tile_layout(pkg, orc, table):
+    """ld_dfire_tile_layout: a permutation of the atoms with padding at the tail, a bijective
+    renumbering of the 169 types, and more atoms whose patch partner type (number ^ 1) sits in their
+    own subtile than with the reference's type numbers on the purely geometric order."""
+    from conftest import case_kwargs
+    method, rec, lig, kw = case_kwargs("1ppe", orc, table)
+    m = orc.Scorer(method, rec, lig, **kw).model(0)
+    xyz, types = m["coordinates"], m["dfire_types"]
+    n = len(xyz)
+    order, perm = pkg.dfire_tile_layout(xyz, types)
+    assert order.size == (n + 63) // 64 * 64 and np.array_equal(np.sort(order[:n]), np.arange(n)) and np.all(order[n:] == 0xFFFFFFFF)
+    assert np.array_equal(np.sort(perm), np.arange(169))
+
+    def partnered(o, numbers):
+        have = tot = 0
+        for k in range(0, n - 7, 8):
+            ids = numbers[types[o[k:k + 8]]]
+            present = set(ids.tolist())
+            have += sum((int(x) ^ 1) in present for x in ids)
+            tot += 8
+        return have / tot
+
+    geometric = pkg.spatial_tile_order(xyz)
+    assert partnered(order, perm) > partnered(geometric, np.arange(169)) + 0.15
+    assert partnered(order, perm) > 0.6

@@ -13,12 +13,14 @@ lig = pkg.model_from_pdb("dfire", os.path.join(g, files[1]))
 pos = orc.parse_positions(os.path.join(g, "initial_positions_0.dat"))[:, :7]
 lut, steps, iface = pkg.dfire_bin_lut()
 def order(m):
-    o = pkg.spatial_tile_order(m["coordinates"])
+    o, perm = pkg.dfire_tile_layout(m["coordinates"], m["dfire_types"])     # what the scorer uses
     pad = o == 0xFFFFFFFF
     idx = np.where(pad, 0, o).astype(np.int64)
     c = m["coordinates"][idx].copy(); t = m["dfire_types"][idx].astype(np.int64)
     c[pad] = 1e9 if m is rec else -1e9
+    PERMS[id(m)] = perm.astype(np.int64)
     return c, t, ~pad
+PERMS = {}
 rc, rt, rv = order(rec); lc0, lt, lv = order(lig)
 def rotmat(q):
     w,x,y,z = q/np.linalg.norm(q)
@@ -34,27 +36,7 @@ def bin_of(d2):
     b = (lut[cell] & 31).astype(np.int64)
     b = b + (d2 >= steps[np.minimum(b+1, 20)])   # exact step
     return b
-def pair_types(c, t, v):
-    """the library's type renumbering (host/spatial_order.cpp: pair_types_for_patches), restated"""
-    n = len(c) // 8
-    C = np.zeros((169, 169))
-    cc = c.reshape(n, 8, 3); tt = t.reshape(n, 8); vv = v.reshape(n, 8)
-    for s_ in range(n):
-        for i in range(8):
-            for j in range(i + 1, 8):
-                if vv[s_, i] and vv[s_, j] and tt[s_, i] != tt[s_, j]:
-                    w = 1.0 / (1.0 + ((cc[s_, i] - cc[s_, j]) ** 2).sum())
-                    C[tt[s_, i], tt[s_, j]] += w; C[tt[s_, j], tt[s_, i]] += w
-    perm = -np.ones(169, dtype=np.int64); nxt = 0
-    edges = sorted(((-C[a, b], a, b) for a in range(169) for b in range(a + 1, 169) if C[a, b] > 0))
-    for w, a, b in edges:
-        if perm[a] < 0 and perm[b] < 0:
-            perm[a], perm[b] = nxt, nxt + 1; nxt += 2
-    for a in range(169):
-        if perm[a] < 0:
-            perm[a] = nxt; nxt += 1
-    return perm
-numberings = {"reference type numbers": (lt, rt), "types paired per molecule (library)": (pair_types(lc0, lt, lv)[lt], pair_types(rc, rt, rv)[rt])}
+numberings = {"reference type numbers": (lt, rt), "types paired per molecule (library)": (PERMS[id(lig)][lt], PERMS[id(rec)][rt])}
 shapes = [(1,1,16),(1,16,1),(1,8,2),(1,4,4),(2,8,1),(4,4,1),(2,4,2),(4,2,2),(2,2,4),(4,1,4),(8,1,2),(1,8,1),(2,2,2),(1,1,8),(2,4,4),(4,4,4)]
 counts = {(k, sh): 0 for k in numberings for sh in shapes}
 hits_total = 0; blocks_total = 0
