@@ -487,11 +487,12 @@ def test_degenerate_poses_neither_hang_nor_poison_the_batch(scorers, orc, name):
 
 
 def test_gso_odd_sizes(pkg, scorers, orc):
-    """1 glowworm (never has a neighbour), 3 glowworms, and more glowworms than threads in a
-    workgroup (1030 > 1024): same as the oracle."""
+    """1 glowworm (never has a neighbour), 3 glowworms, more glowworms than threads in a
+    workgroup (1030 > 1024), and a swarm whose LDS snapshot exceeds 64 KiB (2100): same as the
+    oracle."""
     hip, cpu = scorers("1ppe")
     base = case_positions("1ppe", orc)
-    for n, steps in ((1, 3), (3, 5), (1030, 3)):
+    for n, steps in ((1, 3), (3, 5), (1030, 3), (2100, 2)):
         pos = pkg.synth.jitter(base, n, seed=n) if n > 200 else base[:n]
         gso, ref = pkg.GSO(hip, pos), orc.GSO(cpu, pos)
         for _ in range(steps):
