@@ -99,6 +99,49 @@ def test_dfire_synthetic_table_energy_is_deterministic(orc, table):
     assert e == score + stats[2] * score + stats[3] * score
 
 
+def test_dfire_energy_against_a_vectorised_numpy_restatement(orc, table):
+    """A second, differently written restatement of src/dfire.rs:265-362 (numpy, all pairs at
+    once, the sqrt-based bin of the reference with DIST_TO_BINS spelled out from its rule) must
+    agree with the C oracle on real fixtures: guards the oracle itself, since no DFIRE golden can
+    be reproduced without the real table."""
+    dist_to_bins = [1, 1, 1] + [i - 1 for i in range(3, 15)] + [14 + (i - 15) // 2 for i in range(15, 49)] + [31, 32]
+    assert len(dist_to_bins) == 51 and dist_to_bins[29] == 21 and dist_to_bins[28] == 20      # src/dfire.rs:49-53
+    for name in ("1ppe", "1k4c"):
+        method, rec, lig, kw = case_kwargs(name, orc, table)
+        s = orc.Scorer(method, rec, lig, **kw)
+        mr, ml = s.model(0), s.model(1)
+        poses = case_positions(name, orc)[:3]
+        for p in poses:
+            t, q = p[:3], p[3:7]
+            w, x, y, z = q
+            n2 = w * w + x * x + y * y + z * z                                   # rotate divides by |q|^2, src/qt.rs:48-61
+            R = np.array([[w*w+x*x-y*y-z*z, 2*(x*y-w*z), 2*(x*z+w*y)],
+                          [2*(x*y+w*z), w*w-x*x+y*y-z*z, 2*(y*z-w*x)],
+                          [2*(x*z-w*y), 2*(y*z+w*x), w*w-x*x-y*y+z*z]]) / n2
+            lc = ml["coordinates"] @ R.T + t
+            d2 = ((mr["coordinates"][:, None, :] - lc[None, :, :]) ** 2).sum(-1)
+            hit = d2 <= 225.0
+            d = np.sqrt(d2[hit]) * 2.0 - 1.0
+            idx = np.maximum(d, 0.0).astype(np.int64)                            # `d as usize` saturates below 0
+            bins = np.array(dist_to_bins)[idx] - 1
+            ti = np.broadcast_to(mr["dfire_types"][:, None], d2.shape)[hit].astype(np.int64)
+            tj = np.broadcast_to(ml["dfire_types"][None, :], d2.shape)[hit].astype(np.int64)
+            raw = table[ti * 169 * 20 + tj * 20 + bins].sum()                      # src/dfire.rs:338
+            score = (raw * 0.0157 - 4.7) * -1.0
+            iface = hit.copy()
+            iface[hit] = d <= 3.9
+            rec_if = set(np.flatnonzero(iface.any(1)).tolist())
+            offs, atoms = mr["restraint_offsets"], mr["restraint_atoms"]
+            groups = len(offs) - 1
+            sat = sum(1 for g in range(groups) if rec_if & set(atoms[offs[g]:offs[g + 1]].tolist()))
+            perc = sat / groups if groups else 0.0
+            beads = mr["membrane"]
+            pen = 999.0 * (len(rec_if & set(beads.tolist())) / len(beads)) if len(beads) else 0.0
+            want = score + perc * score - pen
+            got = s.energy_row(p)
+            assert abs(got - want) <= 1e-9 * max(1.0, abs(want)), (name, got, want)
+
+
 def test_unsupported_atoms_are_errors(orc, table, tmp_path):
     """src/dfire.rs:43,180 panics -> constructor errors."""
     bad = tmp_path / "bad.pdb"
