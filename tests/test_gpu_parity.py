@@ -609,6 +609,25 @@ def test_pydock_method(pkg, orc, scorers, tmp_path):
     assert np.all(np.abs(got[4] - want[4]) <= 1.01e-8 + 1e-9 * np.abs(want[4]))
 
 
+def test_c_example_client(pkg, tmp_path):
+    """examples/dna_energy.c: a plain C program against include/lightdock_hip.h reproduces the
+    reference's DNA known answer (src/dna.rs:571) and runs a batch."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "dna_energy"
+    lib_dir = os.path.dirname(pkg.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", pkg.INCLUDE_DIR,
+                        os.path.join(root, "examples", "dna_energy.c"), "-L", lib_dir, "-llightdock_hip",
+                        "-Wl,-rpath," + lib_dir, "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = os.path.join(GOLDEN, "unit", "1azp")
+    r = subprocess.run([str(exe), os.path.join(d, "1azp_receptor.pdb"), os.path.join(d, "1azp_ligand.pdb")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert abs(float(lines[0].split(":")[1]) - (-364.88126358158974)) < 1e-10 * 364.9
+    assert len(lines) == 5 and abs(float(lines[1].split(":")[1]) - float(lines[0].split(":")[1])) < 1e-9   # x = 0 again
+
+
 def test_multi_swarm_launcher(pkg, tmp_path):
     """launch.py (the ant_thony.py replacement): three swarms in one batched GSO write the same
     files as three runs of the single-swarm CLI."""
