@@ -56,6 +56,22 @@ def main():
         print(json.dumps({"what": "gso 1ppe dfire", "swarms": args.swarms, "glowworms": 200, "steps": args.steps,
                           "steps_per_s": args.steps / dt, "evals_per_s": (e1 - e0) / dt,
                           "swarm_steps_per_s": args.steps * args.swarms / dt}))
+    if "gso1k4c" in what:       # the headline system inside the GSO loop: every swarm starts from the example's
+        d4 = os.path.join(g, "1k4c")   # 200 poses with its own seeded jitter
+        s4 = pkg.Scorer.from_pdb("dfire", os.path.join(d4, "lightdock_receptor_membrane.pdb"),
+                                 os.path.join(d4, "lightdock_ligand.pdb"), potential=table)
+        base4 = positions(os.path.join(d4, "initial_positions_0.dat"), 7)
+        pos = np.stack([base4] + [pkg.synth.jitter(base4, 200, seed=k) for k in range(1, args.swarms)])
+        gso = pkg.GSO(s4, pos)
+        gso.run(4)
+        e0 = gso.num_evals
+        t0 = time.perf_counter()
+        gso.run(args.steps)
+        e1 = gso.num_evals
+        dt = time.perf_counter() - t0
+        print(json.dumps({"what": "gso 1k4c dfire", "swarms": args.swarms, "glowworms": 200, "steps": args.steps,
+                          "steps_per_s": args.steps / dt, "evals_per_s": (e1 - e0) / dt,
+                          "swarm_steps_per_s": args.steps * args.swarms / dt}))
     if "k1" in what:
         base = positions(os.path.join(d, "initial_positions_0.dat"), 7)
         poses = pkg.synth.jitter(base, args.batch * 4, seed=3)
