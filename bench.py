@@ -128,6 +128,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the pose-energy path has no CPU fallback")
+    if local >= torch.cuda.device_count():      # ranks that each see only their own GPU (HIP_VISIBLE_DEVICES per rank)
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
