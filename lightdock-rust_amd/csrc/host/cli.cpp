@@ -83,6 +83,8 @@ const std::vector<std::string> &restraint_list(const std::optional<std::map<std:
 }  // namespace
 
 int cli_main(int argc, char **argv) {
+    // one swarm per process: 200 poses per launch, tune the scorer for latency (scorer.cpp, build_tiled)
+    setenv("LIGHTDOCK_TILED_LATENCY", "1", /* overwrite */ 0);
     if (argc != 5) {
         std::fprintf(stderr, "Wrong command line. Usage: %s setup_filename swarm_filename steps method\n",
                      argc > 0 ? argv[0] : "lightdock-hip");
