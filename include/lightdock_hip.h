@@ -226,6 +226,10 @@ int ld_gso_read(ld_gso *g, size_t swarm, double *poses, double *luciferin, doubl
 
 /* Swarm::save (src/swarm.rs:128-167): writes "<dir>/gso_<step>.out" for one swarm. */
 int ld_gso_save(ld_gso *g, size_t swarm, uint32_t step, const char *dir);
+/* The same for many swarms of one ld_gso at once (what a multi-swarm launcher does after a save
+ * step): dirs[k] receives swarm swarms[k].  The state is copied from the device once and the files
+ * are written by a few host threads. */
+int ld_gso_save_many(ld_gso *g, size_t n, const size_t *swarms, const char *const *dirs, uint32_t step);
 
 /* ------------------------------------------------------------------------------------
  * The reference command line (src/bin/lightdock-rust.rs:77-333) as a function:

@@ -457,6 +457,14 @@ class GSO:
     def save(self, swarm, step, directory):
         _check(self.lib.ld_gso_save(self._h, swarm, step, os.fsencode(directory)))
 
+    def save_many(self, swarms, step, directories):
+        """gso_<step>.out of many swarms in one call (one device read, files written by threads)."""
+        n = len(swarms)
+        ids = (C.c_size_t * n)(*[int(s) for s in swarms])
+        dirs = (C.c_char_p * n)(*[os.fsencode(d) for d in directories])
+        self.lib.ld_gso_save_many.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32]
+        _check(self.lib.ld_gso_save_many(self._h, n, ids, dirs, step))
+
 
 def cli_main(argv):
     """The reference command line, in process (src/bin/lightdock-rust.rs:77-333)."""

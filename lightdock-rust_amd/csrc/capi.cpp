@@ -329,6 +329,18 @@ int ld_gso_save(ld_gso *g, size_t swarm, uint32_t step, const char *dir) {
     });
 }
 
+int ld_gso_save_many(ld_gso *g, size_t n, const size_t *swarms, const char *const *dirs, uint32_t step) {
+    return guarded([&] {
+        if (!g || (n && (!swarms || !dirs))) throw ld::Error(LD_ERR_INVALID, "null argument");
+        std::vector<std::string> d(n);
+        for (size_t k = 0; k < n; k++) {
+            if (!dirs[k]) throw ld::Error(LD_ERR_INVALID, "null directory");
+            d[k] = dirs[k];
+        }
+        g->impl.save_many(std::vector<size_t>(swarms, swarms + n), step, d);
+    });
+}
+
 int ld_cli_main(int argc, char **argv) {
     int code = 0;
     int rc = guarded([&] { code = ld::cli_main(argc, argv); });

@@ -30,11 +30,19 @@ class Gso {
     void read(size_t swarm, double *poses, double *luciferin, double *vision, double *scoring, int32_t *n_neighbors,
               int32_t *moved, int32_t *target);
     void save(size_t swarm, uint32_t step, const std::string &dir);  // Swarm::save, src/swarm.rs:128-167
+    void save_many(const std::vector<size_t> &swarms, uint32_t step, const std::vector<std::string> &dirs);
 
    private:
     Scorer &scorer_;
     size_t n_swarms_, n_glowworms_, pose_len_;
     uint32_t steps_done_ = 0;
+    // host copy of the printed state of all swarms, refreshed once per step by save()
+    void refresh_mirror();
+    void write_swarm(size_t swarm, uint32_t step, const std::string &dir) const;  // from the mirror
+    std::vector<double> mirror_poses_, mirror_luc_, mirror_vis_, mirror_sco_;
+    std::vector<int32_t> mirror_nn_;
+    uint32_t mirror_step_ = 0;
+    bool mirror_valid_ = false;
     DeviceArena arena_;
     double *poses_[2] = {nullptr, nullptr};
     int cur_ = 0;

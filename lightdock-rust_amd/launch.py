@@ -90,8 +90,7 @@ def main(argv=None):
             gso.run(nxt - done)
             done = nxt
             if done % 10 == 0 or done == 1:
-                for k, s in enumerate(mine):
-                    gso.save(k, done, "swarm_%d" % s)
+                gso.save_many(range(len(mine)), done, ["swarm_%d" % s for s in mine])
         best = {s: float(gso.read(k)["scoring"].max()) for k, s in enumerate(mine)}
     else:
         best = {}
