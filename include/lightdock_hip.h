@@ -122,6 +122,19 @@ void ld_model_destroy(ld_model *m);
  * lut: 901 cells of 0.25 A^2; steps[b], b = 0..20: first d2 the reference puts in bin >= b.
  * interface_d2: the largest d2 whose d = sqrt(d2)*2-1 is <= 3.9 (src/dfire.rs:339). */
 int ld_dfire_bin_lut(uint8_t *lut_out /* 901 */, double *steps_out /* 21 */, double *interface_d2_out);
+/* The cell LUT of the default DFIRE kernel, which tests pairs in f32 and recomputes in f64 only
+ * where the f32 distance cannot decide the reference's result (host-side, no GPU; for tests).
+ * With D' = cells_per_unit * 4 d2 + 1/2 evaluated in f32 on coordinates within `ubound` of the
+ * frame centre (record units), word = words_out[min((unsigned)D', 1024 * cells_per_unit)]:
+ *   word < 0x00800000            byte offset of the bin within a table patch: every f64 d2 that can
+ *                                produce this cell has that bin, is inside the cutoff, sets no flag
+ *   word == 0x00800000           every such d2 is beyond the cutoff (src/dfire.rs:334)
+ *   word & 0x40000000            flagged: (word >> 24) & 15 == 1: one bin step exactly at the cell's
+ *                                middle, bits 0..11 the offset below it, bits 12..23 its growth above;
+ *                                other codes: decided by comparisons on the f64 distance.
+ * eps_out: the bound on |D_f32 - 4 d2| (units of 4 d2) the LUT was built for.
+ * words_out: 1028 * cells_per_unit entries; cells_per_unit is 1 or 2. */
+int ld_dfire_packed_lut(int cells_per_unit, double ubound, uint32_t *words_out, double *eps_out);
 /* The atom order the tiled DFIRE kernel uses (host-side, no GPU): order_out[slot] = original atom
  * index, UINT32_MAX for padding; length = ceil(n/64)*64.  Consecutive 8 slots ("subtile") and 64
  * slots ("tile") are spatially compact; padding only at the tail.  The energy is a plain sum over

@@ -126,6 +126,7 @@ def load_library():
     lib.ld_model_view.argtypes = [vp, C.POINTER(_Molecule)]
     lib.ld_model_destroy.argtypes = [vp]
     lib.ld_dfire_bin_lut.argtypes = [vp, vp, C.POINTER(C.c_double)]
+    lib.ld_dfire_packed_lut.argtypes = [C.c_int, C.c_double, vp, C.POINTER(C.c_double)]
     lib.ld_stdrng_key.argtypes = [C.c_uint64, vp]
     lib.ld_spatial_tile_order.restype = sz
     lib.ld_spatial_tile_order.argtypes = [vp, sz, vp]
@@ -211,6 +212,14 @@ def dfire_bin_lut():
     d2 = C.c_double()
     _check(load_library().ld_dfire_bin_lut(_ptr(lut), _ptr(steps), C.byref(d2)))
     return lut, steps, d2.value
+
+
+def dfire_packed_lut(cells_per_unit=2, ubound=256.0):
+    """(words, eps) of the default DFIRE kernel's cell LUT, see ld_dfire_packed_lut in the header."""
+    words = np.zeros(1028 * cells_per_unit, dtype=np.uint32)
+    eps = C.c_double()
+    _check(load_library().ld_dfire_packed_lut(cells_per_unit, ubound, _ptr(words), C.byref(eps)))
+    return words, eps.value
 
 
 def spatial_tile_order(xyz):

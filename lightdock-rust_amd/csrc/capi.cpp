@@ -2,6 +2,7 @@
 //
 // Every call catches ld::Error and turns it into an ld_status plus a thread-local
 // message, which is how this library reports what the reference reports by panicking.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -161,6 +162,16 @@ int ld_dfire_bin_lut(uint8_t *lut_out, double *steps_out, double *interface_d2_o
         if (lut_out) std::memcpy(lut_out, t.lut.data(), 901);
         if (steps_out) std::memcpy(steps_out, t.step.data(), 21 * sizeof(double));
         if (interface_d2_out) *interface_d2_out = ld::dfire_interface_d2();
+    });
+}
+int ld_dfire_packed_lut(int cells_per_unit, double ubound, uint32_t *words_out, double *eps_out) {
+    return guarded([&] {
+        if (cells_per_unit != 1 && cells_per_unit != 2) throw ld::Error(LD_ERR_INVALID, "cells_per_unit must be 1 or 2");
+        if (!(ubound > 0.0)) throw ld::Error(LD_ERR_INVALID, "ubound must be positive");
+        const double eps = (double)std::nextafter((float)ld::dfire_f32_error_bound(ubound, cells_per_unit), INFINITY);
+        const std::vector<uint32_t> words = ld::build_packed_lut(cells_per_unit, eps);
+        if (words_out) std::memcpy(words_out, words.data(), words.size() * sizeof(uint32_t));
+        if (eps_out) *eps_out = eps;
     });
 }
 size_t ld_spatial_tile_order(const double *xyz, size_t n, uint32_t *order_out) {

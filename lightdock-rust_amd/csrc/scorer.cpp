@@ -295,8 +295,11 @@ Scorer::Scorer(const ld_scorer_desc &desc) {
 
     if (method_ == LD_METHOD_DFIRE) {
         const char *k = std::getenv("LIGHTDOCK_DFIRE_KERNEL");
+        // "packed" (default): culling + packed-f32 pair test with exact f64 path; "tiled": the same
+        // culling with an all-f64 pair test; "allpairs": no culling
         use_tiled_ = !(k && std::strcmp(k, "allpairs") == 0);
         if (use_tiled_) build_tiled(desc);
+        if (use_tiled_ && !(k && std::strcmp(k, "tiled") == 0)) build_packed(desc);
     }
 }
 
@@ -438,6 +441,167 @@ void Scorer::build_tiled(const ld_scorer_desc &desc) {
     }
 }
 
+// The cell LUT of the packed DFIRE kernel (kernels/dfire_packed.hpp) for `sc` cells per unit of
+// 4 d2 and an f32 distance error of at most `eps` (units of 4 d2).
+std::vector<uint32_t> build_packed_lut(int sc, double eps) {
+    // cell LUT.  Cell k holds the pairs with D' = sc * 4 d2 + 1/2 (f32) in [k, k+1), i.e. a true
+    // 4 d2 within ((k - 1/2) / sc - eps, (k + 1/2) / sc + eps); the last cell everything further.
+    const DfireBinning b = build_dfire_binning();
+    const double e = eps;
+    const double iface_scaled = 4.0 * dfire_interface_d2();
+    const int n_cells = 1024 * sc;
+    std::vector<uint32_t> words((size_t)kPackedLutCells * sc, kPackedMiss);
+    for (int k = 0; k < n_cells; k++) {
+        const double ilo = (k - 0.5) / sc - e, ihi = (k + 0.5) / sc + e;
+        if (ilo > 900.0) continue;  // beyond the cutoff for sure
+        uint32_t code = 0;
+        int steps_inside = 0, base_bin = 0, step_bin = 0;
+        double step_at = 0.0;
+        for (int s = 1; s <= 20; s++) {
+            const double at = 4.0 * b.step[s];
+            if (at < ilo) base_bin = s;  // already in bin s at the lower end
+            else if (at <= ihi) {
+                steps_inside++;
+                step_bin = s;
+                step_at = at;
+            }
+        }
+        if (steps_inside > 1) throw Error(LD_ERR_INVALID, "DFIRE cell LUT: two bin steps in one cell");
+        if (steps_inside) code |= kPackedCodeStep;
+        const bool below_iface = ihi < iface_scaled;  // every pair of the cell sets interface flags
+        if (ilo <= iface_scaled && !below_iface) code |= kPackedCodeIface;
+        if (ihi >= 900.0) code |= kPackedCodeCutoff;
+        if (!code && !below_iface) {
+            if (dfire_bin_reference(std::max(ilo, 0.0) / 4.0) != base_bin || dfire_bin_reference(ihi / 4.0) != base_bin)
+                throw Error(LD_ERR_INVALID, "DFIRE cell LUT self-check failed in cell " + std::to_string(k));
+            words[k] = tiled_bin_term((uint32_t)base_bin);
+            continue;
+        }
+        // Lean form: the only step of the cell sits at its middle (the squares (n+1)^2 are integers;
+        // the exact first double of a bin can lie an ulp below, where the correctly rounded sqrt of
+        // the reference rounds up onto the step -- far inside the eps band that goes to the exact
+        // path anyway) and everything below / above it has one answer.  The cutoff cell is lean
+        // when the last bin step and the cutoff coincide at 900: above it = miss.
+        const bool mid = steps_inside == 1 && std::fabs(step_at * sc - (double)k) <= 1e-9 && step_bin == base_bin + 1;
+        const uint32_t flags_code = below_iface ? kPackedCodeFlags : 0u;
+        if (code == 0) {  // below the interface distance, no step: lean with nothing to grow by
+            words[k] = kPackedSlow | ((kPackedCodeLean | flags_code) << 24) | tiled_bin_term((uint32_t)base_bin);
+        } else if (code == kPackedCodeStep && mid) {
+            const uint32_t below = tiled_bin_term((uint32_t)base_bin);
+            words[k] = kPackedSlow | ((kPackedCodeLean | flags_code) << 24) | ((tiled_bin_term((uint32_t)base_bin + 1) - below) << 12) | below;
+        } else if (code == (kPackedCodeStep | kPackedCodeCutoff) && mid && std::fabs(step_at - 900.0) <= 1e-9 && base_bin == 19) {
+            // beyond the cutoff = the unused bin slot 21 of the same patch group, which holds 0.0
+            const uint32_t below = tiled_bin_term(19u);
+            words[k] = kPackedSlow | (kPackedCodeLean << 24) | ((tiled_bin_term(21u) - below) << 12) | below;
+        } else {
+            words[k] = kPackedSlow | (code << 24) | ((uint32_t)step_bin << 16);
+        }
+    }
+    return words;
+}
+
+// The default DFIRE kernel: f32 records in a frame centred on the receptor, the cell LUT of
+// kernels/dfire_packed.hpp (every cell that cannot decide the reference's f64 result is flagged),
+// and the receptor image as pair records.
+void Scorer::build_packed(const ld_scorer_desc &desc) {
+    const ld_molecule &rec = desc.receptor;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (size_t i = 0; i < rec.n_atoms; i++)
+        for (int c = 0; c < 3; c++) {
+            lo[c] = std::min(lo[c], rec.coordinates[3 * i + c]);
+            hi[c] = std::max(hi[c], rec.coordinates[3 * i + c]);
+        }
+    double centre[3], half = 0.0;
+    for (int c = 0; c < 3; c++) {
+        centre[c] = 0.5 * (lo[c] + hi[c]);
+        half = std::max(half, 0.5 * (hi[c] - lo[c]));
+    }
+    // LUT cells per unit of 4 d2: 2 halves the share of pairs in flagged cells for 4 KiB more LDS
+    int sc = 2;
+    if (const char *e = std::getenv("LIGHTDOCK_PACKED_CELLS")) sc = std::atoi(e) == 1 ? 1 : 2;
+    const double kappa = 2.0 * std::sqrt((double)sc);
+    // records hold kappa (x - c); room for the cutoff and for ANM deformations (32 A), rounded up to a power of two
+    double ubound = 128.0;
+    while (ubound < kappa * (half + 32.0)) ubound *= 2.0;
+    double eps = dfire_f32_error_bound(ubound, sc);  // units of 4 d2
+    if (const char *e = std::getenv("LIGHTDOCK_PACKED_EPS_SCALE")) {  // test hook: results must not depend on it
+        const double f = std::atof(e);
+        if (f >= 1.0 && f <= 1000.0) eps *= f;
+    }
+    if (!(eps * sc < 0.2)) return;  // a receptor thousands of angstroms across: keep the all-f64 tiled kernel
+
+    PackedLaunch &P = packed_;
+    P.lig = tiled_.lig;
+    P.use_anm = tiled_.use_anm;
+    P.anm_rec = tiled_.anm_rec;
+    P.cx = centre[0];
+    P.cy = centre[1];
+    P.cz = centre[2];
+    P.kappa = kappa;
+    P.cells_per_unit = sc;
+    P.ubound = (float)ubound;
+    P.eps = std::nextafter((float)eps, INFINITY);
+    P.table = tiled_.table;
+    P.bin_step = pair_.bin_step;
+    P.iface_scaled = 4.0 * pair_.iface_d2;
+
+    P.lut = arena_.upload(build_packed_lut(sc, (double)P.eps));
+
+    int split = tiled_.split;
+    P.split = split;
+    P.n_groups = (P.lig.n_tiles * split + kPackedWaves - 1) / kPackedWaves;
+
+    P.rec.n_real = tiled_rec_soa_.n_real;
+    P.rec.n_tiles = tiled_rec_soa_.n_tiles;
+    P.rec.flag_words = pair_.rec.flag_words;
+    P.rec.slot = tiled_rec_soa_.slot;
+    P.rec.tindex = tiled_rec_soa_.tindex;
+    if (!rec_anm_per_pose_) {
+        const size_t pad = (size_t)P.rec.n_tiles * 64;
+        PackedRecPair *pairs = static_cast<PackedRecPair *>(arena_.alloc_bytes(pad / 2 * sizeof(PackedRecPair)));
+        TiledBox *sub = static_cast<TiledBox *>(arena_.alloc_bytes(pad / 8 * sizeof(TiledBox)));
+        TiledBox *tile = static_cast<TiledBox *>(arena_.alloc_bytes(pad / 64 * sizeof(TiledBox)));
+        PackedPrepareLaunch p = packed_prepare_launch(nullptr, 0, nullptr, 1);
+        p.num_anm = 0;
+        p.pairs_out = pairs;
+        p.sub_out = sub;
+        p.tile_out = tile;
+        p.xyz_out = nullptr;
+        hip_check(launch_packed_prepare(p, stream_), "launch dfire_packed_prepare");
+        hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        P.rec.pairs = pairs;
+        P.rec.sub_boxes = sub;
+        P.rec.tile_boxes = tile;
+        P.rec.x = tiled_rec_soa_.x;
+        P.rec.y = tiled_rec_soa_.y;
+        P.rec.z = tiled_rec_soa_.z;
+    }
+    use_packed_ = true;
+}
+
+PackedPrepareLaunch Scorer::packed_prepare_launch(const double *poses, size_t stride, const uint8_t *active, size_t n) const {
+    PackedPrepareLaunch p;
+    p.n_real = tiled_rec_soa_.n_real;
+    p.n_tiles = tiled_rec_soa_.n_tiles;
+    p.x = tiled_rec_soa_.x;
+    p.y = tiled_rec_soa_.y;
+    p.z = tiled_rec_soa_.z;
+    p.tindex = tiled_rec_soa_.tindex;
+    p.slot = tiled_rec_soa_.slot;
+    p.num_anm = tiled_rec_soa_.num_anm;
+    p.modes = tiled_rec_soa_.modes;
+    p.poses = poses;
+    p.stride = stride;
+    p.active = active;
+    p.n_poses = n;
+    p.cx = packed_.cx;
+    p.cy = packed_.cy;
+    p.cz = packed_.cz;
+    p.kappa = packed_.kappa;
+    p.ubound = packed_.ubound;
+    return p;
+}
+
 PrepareReceptorLaunch Scorer::prepare_launch(const double *poses, size_t stride, const uint8_t *active, size_t n) const {
     PrepareReceptorLaunch p;
     p.n_real = tiled_rec_soa_.n_real;
@@ -472,18 +636,22 @@ Scorer::~Scorer() {
     ws_rec_atoms_.release();
     ws_rec_sub_.release();
     ws_rec_tile_.release();
+    ws_rec_pairs_.release();
+    ws_rec_xyz_.release();
+    ws_exact_.release();
     ws_poses_.release();
     ws_energies_.release();
 }
 
 void Scorer::reserve_workspace(size_t n_poses, bool counts) {
     const size_t words = (size_t)(pair_.rec.flag_words + pair_.lig.flag_words);
-    const size_t chunks = (size_t)std::max(pair_.n_chunks, use_tiled_ ? tiled_.n_groups : 0);
+    const size_t chunks = (size_t)std::max(pair_.n_chunks, use_packed_ ? packed_.n_groups : use_tiled_ ? tiled_.n_groups : 0);
     ws_partial_.reserve(n_poses * chunks * 2 * sizeof(double));
     ws_flags_.reserve(std::max<size_t>(n_poses * words * sizeof(uint32_t), 16));
     if (counts) {
         ws_counts_.reserve(n_poses * chunks * sizeof(uint32_t));
         ws_tested_.reserve(n_poses * chunks * sizeof(uint32_t));
+        ws_exact_.reserve(n_poses * chunks * sizeof(uint32_t));
     }
 }
 
@@ -496,7 +664,8 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
         // every pose carries its own deformed receptor image: bound that workspace (8 GiB) by
         // slicing very large batches; poses are independent, so the results do not change
         const size_t pad = (size_t)tiled_.rec.n_tiles * 64;
-        const size_t per_pose = pad * sizeof(TiledAtom) + (pad / 8 + pad / 64) * sizeof(TiledBox);
+        const size_t per_pose = (use_packed_ ? pad / 2 * sizeof(PackedRecPair) + 3 * pad * sizeof(double) : pad * sizeof(TiledAtom)) +
+                                (pad / 8 + pad / 64) * sizeof(TiledBox);
         static const size_t cap = [] {  // LIGHTDOCK_RECEPTOR_IMAGE_MIB: test hook for the slicing
             const char *e = std::getenv("LIGHTDOCK_RECEPTOR_IMAGE_MIB");
             const long v = e ? std::atol(e) : 0;
@@ -542,7 +711,43 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
         }
         hip_check(hipEventRecord(events_[events_used_].first, stream_), "hipEventRecord");
     }
-    if (use_tiled_) {
+    if (use_packed_) {
+        PackedLaunch t = packed_;
+        t.poses = d_poses;
+        t.stride = stride;
+        t.active = d_active;
+        t.n_poses = n;
+        t.partial = p.partial;
+        t.flags = p.flags;
+        t.count_partial = p.count_partial;
+        t.tested_partial = p.count_partial ? static_cast<uint32_t *>(ws_tested_.ptr) : nullptr;
+        t.exact_partial = p.count_partial ? static_cast<uint32_t *>(ws_exact_.ptr) : nullptr;
+        p.n_chunks = t.n_groups;  // the tail kernel folds this many partials
+        if (rec_anm_per_pose_) {  // one deformed receptor image per pose (src/dfire.rs:304-320)
+            const size_t pad = (size_t)t.rec.n_tiles * 64;
+            ws_rec_pairs_.reserve(n * (pad / 2) * sizeof(PackedRecPair));
+            ws_rec_xyz_.reserve(n * 3 * pad * sizeof(double));
+            ws_rec_sub_.reserve(n * (pad / 8) * sizeof(TiledBox));
+            ws_rec_tile_.reserve(n * (pad / 64) * sizeof(TiledBox));
+            PackedPrepareLaunch pr = packed_prepare_launch(d_poses, stride, d_active, n);
+            pr.pairs_out = static_cast<PackedRecPair *>(ws_rec_pairs_.ptr);
+            pr.xyz_out = static_cast<double *>(ws_rec_xyz_.ptr);
+            pr.sub_out = static_cast<TiledBox *>(ws_rec_sub_.ptr);
+            pr.tile_out = static_cast<TiledBox *>(ws_rec_tile_.ptr);
+            hip_check(launch_packed_prepare(pr, stream_), "launch dfire_packed_prepare");
+            t.rec.pairs = pr.pairs_out;
+            t.rec.sub_boxes = pr.sub_out;
+            t.rec.tile_boxes = pr.tile_out;
+            t.rec.x = pr.xyz_out;
+            t.rec.y = pr.xyz_out + pad;
+            t.rec.z = pr.xyz_out + 2 * pad;
+            t.rec.pose_stride_pairs = pad / 2;
+            t.rec.pose_stride_sub = pad / 8;
+            t.rec.pose_stride_tile = pad / 64;
+            t.rec.pose_stride_xyz = 3 * pad;
+        }
+        hip_check(launch_dfire_packed(t, stream_), "launch dfire_packed_pairs");
+    } else     if (use_tiled_) {
         TiledLaunch t = tiled_;
         t.poses = d_poses;
         t.stride = stride;
@@ -610,7 +815,7 @@ void Scorer::energy_batch_host(size_t n, const double *poses, size_t stride, dou
 void Scorer::last_block_counts(size_t n, uint32_t *out_host) {
     if (!use_tiled_) throw Error(LD_ERR_UNSUPPORTED, "block counts exist for the tiled DFIRE kernel only");
     if (!out_host) throw Error(LD_ERR_INVALID, "null output");
-    const size_t groups = (size_t)tiled_.n_groups;
+    const size_t groups = (size_t)(use_packed_ ? packed_.n_groups : tiled_.n_groups);
     if (ws_tested_.bytes < n * groups * sizeof(uint32_t)) throw Error(LD_ERR_INVALID, "no counting launch of that size has run");
     std::vector<uint32_t> part(n * groups);
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
@@ -642,10 +847,10 @@ void Scorer::pair_kernel_time(double *total_ms, uint64_t *launches) {
 }
 
 void Scorer::kernel_info(ld_kernel_info *out) const {
-    out->pair_kernel_name = use_tiled_ ? "dfire_tiled_pairs" : pair_kernel_name(method_);
-    out->block_threads = use_tiled_ ? (uint32_t)tiled_.waves * 64 : (uint32_t)kBlockThreads;
-    out->receptor_chunks = (uint32_t)(use_tiled_ ? tiled_.n_groups : pair_.n_chunks);
-    out->lds_bytes = (uint32_t)(use_tiled_ ? tiled_kernel_lds_bytes(tiled_) : pair_kernel_lds_bytes(pair_));
+    out->pair_kernel_name = use_packed_ ? "dfire_packed_pairs" : use_tiled_ ? "dfire_tiled_pairs" : pair_kernel_name(method_);
+    out->block_threads = use_packed_ ? (uint32_t)kPackedWaves * 64 : use_tiled_ ? (uint32_t)tiled_.waves * 64 : (uint32_t)kBlockThreads;
+    out->receptor_chunks = (uint32_t)(use_packed_ ? packed_.n_groups : use_tiled_ ? tiled_.n_groups : pair_.n_chunks);
+    out->lds_bytes = (uint32_t)(use_packed_ ? packed_kernel_lds_bytes(packed_.cells_per_unit) : use_tiled_ ? tiled_kernel_lds_bytes(tiled_) : pair_kernel_lds_bytes(pair_));
     out->pair_tests_per_pose = (uint64_t)pair_.rec.n * (uint64_t)pair_.lig.n;
     // DFIRE 26 B/atom (3 f64 + u16 type), DNA 48 B/atom (6 f64), + 240 B/atom
     // per ANM-deformed molecule (10 modes x 24 B), + 56 B pose in + 8 B energy out.

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "host/error.hpp"
+#include "kernels/dfire_packed.hpp"
 #include "kernels/dfire_tiled.hpp"
 #include "kernels/pose_energy.hpp"
 #include "lightdock_hip.h"
@@ -61,6 +62,7 @@ struct DfireBinning {
 };
 DfireBinning build_dfire_binning();                  // throws if the self-check fails
 double dfire_interface_d2();                         // largest d2 with sqrt(d2)*2-1 <= 3.9
+std::vector<uint32_t> build_packed_lut(int cells_per_unit, double eps);  // kPackedLutCells * cells_per_unit words
 
 class Scorer {
    public:
@@ -101,6 +103,7 @@ class Scorer {
                          std::vector<uint32_t> &membrane_slots);
     void reserve_workspace(size_t n_poses, bool counts);
     void build_tiled(const ld_scorer_desc &desc);
+    void build_packed(const ld_scorer_desc &desc);  // after build_tiled: shares its table, ligand and tile order
     struct TiledSoA {  // a molecule in tile order, SoA, padded to whole tiles
         int n_real = 0, n_tiles = 0;
         const double *x = nullptr, *y = nullptr, *z = nullptr;
@@ -111,6 +114,7 @@ class Scorer {
     };
     void upload_tiled_molecule(const ld_molecule &m, bool is_receptor, TiledSoA &out);
     PrepareReceptorLaunch prepare_launch(const double *poses, size_t stride, const uint8_t *active, size_t n) const;
+    PackedPrepareLaunch packed_prepare_launch(const double *poses, size_t stride, const uint8_t *active, size_t n) const;
 
     int device_ = 0;
     hipStream_t stream_ = nullptr;
@@ -121,8 +125,11 @@ class Scorer {
     DeviceArena arena_;
     PairLaunch pair_;     // receptor / ligand / table pointers filled once; batch fields per call
     TailTables tail_;
-    bool use_tiled_ = false;  // DFIRE: bounding-box culled kernel (default) instead of all-pairs
+    bool use_tiled_ = false;  // DFIRE: a bounding-box culled kernel instead of all-pairs
     TiledLaunch tiled_;
+    bool use_packed_ = false;  // DFIRE default: culling + packed-f32 pair test with exact f64 path (kernels/dfire_packed.hpp)
+    PackedLaunch packed_;
+    DeviceBuffer ws_rec_pairs_, ws_rec_xyz_, ws_exact_;
     TiledSoA tiled_rec_soa_;          // receptor in tile order (input of dfire_prepare_receptor)
     bool rec_anm_per_pose_ = false;   // receptor ANM: one receptor image per pose per launch
     DeviceBuffer ws_rec_atoms_, ws_rec_sub_, ws_rec_tile_;

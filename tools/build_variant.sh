@@ -1,0 +1,7 @@
+# builds lightdock-rust_amd/lib/variants/<name>.so with extra flags for the DFIRE kernels, next to the normal library
+# usage: bash tools/build_variant.sh <name> [-DFLAG ...]
+name=$1; shift
+cd "$(dirname "$0")/../lightdock-rust_amd" && cp lib/liblightdock_hip.so /tmp/ld_keep.so \
+ && touch csrc/kernels/dfire_packed.hip csrc/kernels/dfire_tiled.hip && make EXTRA_HIPFLAGS="$*" >/dev/null \
+ && mkdir -p lib/variants && cp lib/liblightdock_hip.so lib/variants/$name.so \
+ && touch csrc/kernels/dfire_packed.hip csrc/kernels/dfire_tiled.hip && make >/dev/null && echo built lib/variants/$name.so
