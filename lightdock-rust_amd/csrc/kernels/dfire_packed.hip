@@ -287,14 +287,17 @@ __device__ __forceinline__ bool beyond_cutoff_slot(uint32_t byte_offset) {
     return (d % kTiledRecStride) / kTiledPatchDoubles == 5u && (d % 4u) == 1u;
 }
 
+#ifndef LD_PACKED_MIN_BLOCKS
+#define LD_PACKED_MIN_BLOCKS (32 / kPackedWaves)  // 8 waves per SIMD: at most 64 VGPRs
+#endif
 template <bool COUNT, int SC>
-__global__ __launch_bounds__(kPackedWaves * 64, 8) void dfire_packed_pairs(const PackedLaunch T) {
+__global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_MIN_BLOCKS) void dfire_packed_pairs(const PackedLaunch T) {
     // separate LDS objects: the backend tells the LDS-DMA target apart from the other arrays
     __shared__ __attribute__((aligned(16))) uint32_t s_lut[kPackedLutCells * SC];
     __shared__ __attribute__((aligned(16))) double s_step4[kDfireSteps];
-    __shared__ __attribute__((aligned(16))) LigRecord s_lig[kPackedWaves][64];
-    // receptor tile: 32 pair records + 4 that lie far away (the partner of an odd block left over)
-    __shared__ __attribute__((aligned(32))) PackedRecPair s_rec[kPackedWaves][32 + 4];
+    // ligand tile: 64 records + a ninth subtile that lies far away (the partner of an odd block left over)
+    __shared__ __attribute__((aligned(16))) LigRecord s_lig[kPackedWaves][64 + 8];
+    __shared__ __attribute__((aligned(32))) PackedRecPair s_rec[kPackedWaves][32];
     struct WaveResult {
         double sum;
         uint32_t count, tested, exact, pad;
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(kPackedWaves * 64, 8) void dfire_packed_pairs(const
     for (int i = tid; i < kPackedLutCells * SC / 4; i += kPackedWaves * 64)
         reinterpret_cast<uint4 *>(s_lut)[i] = reinterpret_cast<const uint4 *>(T.lut)[i];
     if (tid < kDfireSteps) s_step4[tid] = 4.0 * T.bin_step[tid];
-    if (lane < 4) s_rec[wave][32 + lane] = PackedRecPair{-1.0e30f, -1.0e30f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+    if (lane < 8) s_lig[wave][64 + lane] = LigRecord{1.0e30f, 0.f, 0.f, 0u};
     __syncthreads();
 
     LigRecord *ligt = s_lig[wave];
@@ -336,7 +339,11 @@ __global__ __launch_bounds__(kPackedWaves * 64, 8) void dfire_packed_pairs(const
     const int bj = lane & 7;                                 // box tests: lane = ligand subtile (lane >> 3) x receptor subtile bj
     const int ph = lane >> 5, pi = (lane >> 2) & 7, pq = lane & 3;  // pair loop: block of the trip, ligand atom, record
     double acc = 0.0, pend0 = 0.0, pend1 = 0.0;
+#ifdef LD_PACKED_DEPTH2
+    double pendB0 = 0.0, pendB1 = 0.0;
+#endif
     uint32_t cnt = 0, tested = 0, n_exact = 0;
+    const uint32_t half_shift = (uint32_t)ph * 32u;
     uint32_t queued = 0;  // wave-uniform; beyond kPackedQueue the wave redoes its tile in f64 (overflow pass)
     constexpr float kCellMax = kPackedCellMax * SC;
     constexpr float kBoxCut = kCut2Padded * SC;  // boxes live in the record frame
@@ -426,16 +433,17 @@ __global__ __launch_bounds__(kPackedWaves * 64, 8) void dfire_packed_pairs(const
                 // left over is paired with the far-away records behind the tile (all misses).
                 while (smask) {
                     LD_STAMP(n_trips++;)
+                    // bit k of smask = block (ligand subtile k >> 3, receptor subtile k & 7); 64 = the far-away
+                    // ligand subtile x receptor subtile 0.  Each half of the wave picks its block out of the
+                    // scalar pair with one 64-bit shift.
                     const int k0 = __ffsll(smask) - 1;
-                    smask &= smask - 1;
-                    const int k1 = smask ? __ffsll(smask) - 1 : 64;  // 64: ligand subtile 0 x the far-away subtile
-                    smask &= smask - 1;
-                    // byte offsets of the two blocks' subtiles: ligand | receptor << 16
-                    const uint32_t pack0 = (uint32_t)((k0 >> 3) * 128) | (uint32_t)((k0 & 7) * 128) << 16;
-                    const uint32_t pack1 = k1 == 64 ? 1024u << 16 : (uint32_t)((k1 >> 3) * 128) | (uint32_t)((k1 & 7) * 128) << 16;
-                    const uint32_t pack = ph ? pack1 : pack0;
-                    const LigRecord *lp = reinterpret_cast<const LigRecord *>(reinterpret_cast<const unsigned char *>(ligt) + (pack & 0xffffu)) + pi;
-                    const PackedRecPair *rp = reinterpret_cast<const PackedRecPair *>(reinterpret_cast<const unsigned char *>(rect) + (pack >> 16)) + pq;
+                    asm("s_bitset0_b64 %0, %1" : "+s"(smask) : "s"(k0));
+                    const int k1 = smask ? __ffsll(smask) - 1 : 64;
+                    asm("s_bitset0_b64 %0, %1" : "+s"(smask) : "s"(k1));  // bit 64 = bit 0, which is clear by now
+                    const uint32_t kk = (uint32_t)((((unsigned long long)(uint32_t)k1 << 32) | (uint32_t)k0) >> half_shift);
+                    const uint32_t lsub = kk >> 3, rsub = kk & 7u;
+                    const LigRecord *lp = ligt + lsub * 8 + pi;
+                    const PackedRecPair *rp = rect + rsub * 4 + pq;
                     const v4f Lv = *reinterpret_cast<const v4f *>(lp);
                     const v4f Ra = *reinterpret_cast<const v4f *>(rp);
                     const v4f Rb = *reinterpret_cast<const v4f *>(reinterpret_cast<const unsigned char *>(rp) + 16);
@@ -461,31 +469,41 @@ __global__ __launch_bounds__(kPackedWaves * 64, 8) void dfire_packed_pairs(const
                         // flagged addend.
                         bool need0, need1;
                         {
-                            const float d0 = Dp.x - ((float)c0 + 0.5f), d1 = Dp.y - ((float)c1 + 0.5f);
+                            // position inside the cell relative to its middle (cell = floor(D') below the clamp)
+                            const float d0 = __builtin_amdgcn_fractf(Dp.x) - 0.5f, d1 = __builtin_amdgcn_fractf(Dp.y) - 0.5f;
                             const float epsc = T.eps * SC;
-                            const uint32_t la_bit = (pack & 0xffffu) / 16u + (uint32_t)pi, ra_bit = (pack >> 16) / 16u + 2u * (uint32_t)pq;
-                            const bool lt = (lig_tracked >> la_bit) & 1ull;
-                            const bool t0 = lt || ((rec_tracked >> (ra_bit & 63u)) & 1ull), t1 = lt || ((rec_tracked >> ((ra_bit + 1) & 63u)) & 1ull);
-                            const uint32_t lean_plain = (kPackedSlow >> 24) | kPackedCodeLean, lean_flags = lean_plain | kPackedCodeFlags;
-                            const bool lean0 = ((w0 >> 24) == lean_plain || ((w0 >> 24) == lean_flags && !t0)) && (int)off0 >= 0 && fabsf(d0) > epsc;
-                            const bool lean1 = ((w1 >> 24) == lean_plain || ((w1 >> 24) == lean_flags && !t1)) && (int)off1 >= 0 && fabsf(d1) > epsc;
+                            const uint32_t tag0 = w0 & 0xff000000u, tag1 = w1 & 0xff000000u;
+                            constexpr uint32_t lean_plain = kPackedSlow | kPackedCodeLean << 24, lean_flags = lean_plain | kPackedCodeFlags << 24;
+                            const bool clear0 = (int)off0 >= 0 && fabsf(d0) > epsc, clear1 = (int)off1 >= 0 && fabsf(d1) > epsc;
+                            bool lean0 = tag0 == lean_plain && clear0, lean1 = tag1 == lean_plain && clear1;
+                            // cells below the interface distance (clashing atoms): lean too, unless one of the two atoms
+                            // has an interface-flag slot
+                            if (__ballot(tag0 == lean_flags || tag1 == lean_flags) != 0ull) {
+                                const uint32_t la_bit = lsub * 8u + (uint32_t)pi, ra_bit = rsub * 8u + 2u * (uint32_t)pq;
+                                const bool lt = (lig_tracked >> la_bit) & 1ull;
+                                const bool t0 = lt || ((rec_tracked >> (ra_bit & 63u)) & 1ull), t1 = lt || ((rec_tracked >> ((ra_bit + 1) & 63u)) & 1ull);
+                                lean0 = lean0 || (tag0 == lean_flags && !t0 && clear0);
+                                lean1 = lean1 || (tag1 == lean_flags && !t1 && clear1);
+                            }
                             // word = flags | growth << 12 | term below the step
                             const uint32_t f0 = off0 - (w0 & 0xfffff000u) + (d0 < 0.f ? 0u : (w0 >> 12) & 0xfffu);
                             const uint32_t f1 = off1 - (w1 & 0xfffff000u) + (d1 < 0.f ? 0u : (w1 >> 12) & 0xfffu);
-                            const bool real_block = (pack >> 16) < 1024u;  // not the far-away partner of an odd block
-                            need0 = off0 >= kPackedSlow && !lean0 && real_block;
-                            need1 = off1 >= kPackedSlow && !lean1 && real_block;
+                            need0 = off0 >= kPackedSlow && !lean0;
+                            need1 = off1 >= kPackedSlow && !lean1;
                             off0 = lean0 ? f0 : off0;
                             off1 = lean1 ? f1 : off1;
                         }
 #ifndef LD_PACKED_NO_FULL
-                        const unsigned long long m0 = __ballot(need0), m1 = __ballot(need1);
-                        if (__builtin_expect((m0 | m1) != 0ull, 0)) {
+                        if (__builtin_expect(__ballot(need0 || need1) != 0ull, 0)) {
                             // queue them for the exact path (after the loops) and read misses for now
+                            const bool real_block = lsub < 8u;  // not the far-away partner of an odd block
+                            need0 = need0 && real_block;
+                            need1 = need1 && real_block;
+                            const unsigned long long m0 = __ballot(need0), m1 = __ballot(need1);
                             const uint32_t n0 = (uint32_t)__popcll(m0);
                             const uint32_t i0 = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
                             const uint32_t i1 = queued + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-                            const uint32_t item = ((pack & 0xffffu) / 16u + (uint32_t)pi) | (uint32_t)(RT * 64 + (int)((pack >> 16) / 16u) + 2 * pq) << 6;
+                            const uint32_t item = (lsub * 8u + (uint32_t)pi) | (uint32_t)(RT * 64 + (int)(rsub * 8u) + 2 * pq) << 6;
                             if (need0 && i0 < kPackedQueue) s_queue[wave][i0] = item;
                             if (need1 && i1 < kPackedQueue) s_queue[wave][i1] = item + 64u;
                             queued += n0 + (uint32_t)__popcll(m1);
@@ -497,9 +515,17 @@ __global__ __launch_bounds__(kPackedWaves * 64, 8) void dfire_packed_pairs(const
 #endif
                     // retire the previous trip's gathers only now (their L2 latency hides behind
                     // this trip's LDS reads and arithmetic), then issue this trip's
+#ifdef LD_PACKED_DEPTH2
+                    acc += pendB0;
+                    acc += pendB1;
+                    asm volatile("" : "+v"(acc) : : "memory");
+                    pendB0 = pend0;
+                    pendB1 = pend1;
+#else
                     acc += pend0;
                     acc += pend1;
                     asm volatile("" : "+v"(acc) : : "memory");
+#endif
 #ifndef LD_PACKED_NO_GATHER
                     pend0 = table_entry(table, off0);
                     pend1 = table_entry(table, off1);
@@ -530,6 +556,10 @@ __global__ __launch_bounds__(kPackedWaves * 64, 8) void dfire_packed_pairs(const
             acc = 0.0;
             pend0 = 0.0;
             pend1 = 0.0;
+#ifdef LD_PACKED_DEPTH2
+            pendB0 = 0.0;
+            pendB1 = 0.0;
+#endif
             cnt = 0;
             const Vec3 p = pose_ligand_atom(T.lig, T.use_anm, T.anm_rec, row, la);
             const uint32_t lig_term = T.lig.tindex[la];
@@ -553,6 +583,10 @@ __global__ __launch_bounds__(kPackedWaves * 64, 8) void dfire_packed_pairs(const
         }
     }
 
+#ifdef LD_PACKED_DEPTH2
+    acc += pendB0;
+    acc += pendB1;
+#endif
     // ---- 5. reduction ----------------------------------------------------------------------------
     LD_STAMP(if (lane == 0) {
         atomicAdd(&g_ld_stamps[0], __builtin_amdgcn_s_memtime() - ts0);
@@ -608,7 +642,7 @@ double dfire_f32_error_bound(double ubound, int cells_per_unit) {
 
 size_t packed_kernel_lds_bytes(int cells_per_unit) {
     return (size_t)kPackedLutCells * cells_per_unit * sizeof(uint32_t) + kDfireSteps * sizeof(double) +
-           (size_t)kPackedWaves * (64 * sizeof(LigRecord) + 36 * sizeof(PackedRecPair)) + kPackedWaves * 24;
+           (size_t)kPackedWaves * (72 * sizeof(LigRecord) + 32 * sizeof(PackedRecPair) + kPackedQueue * 4) + kPackedWaves * 24;
 }
 
 hipError_t launch_dfire_packed(const PackedLaunch &t, hipStream_t stream) {

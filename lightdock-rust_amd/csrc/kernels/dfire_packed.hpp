@@ -32,7 +32,10 @@
 
 namespace ld {
 
-constexpr int kPackedWaves = 4;          // wave64s per workgroup, one ligand tile each
+#ifndef LD_PACKED_WAVES
+#define LD_PACKED_WAVES 4
+#endif
+constexpr int kPackedWaves = LD_PACKED_WAVES;  // wave64s per workgroup, one ligand tile each
 constexpr int kPackedLutCells = 1028;    // per cell of 4 d2: cells 0..1024 (1024 = everything further), padded to 16 bytes
 constexpr float kPackedCellMax = 1024.0f;
 constexpr int kPackedQueue = 64;         // per wave: pairs waiting for the exact f64 path

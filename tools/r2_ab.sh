@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python tools/debug_packed.py 1ppe 1k4c 2uuy 2>&1 | grep -v "tiled\|allpairs\|amdgpu.ids\|packed1"
-bash tools/ab.sh --steps 10 --warmup 2
-LIGHTDOCK_PACKED_CELLS=1 timeout 100 python bench.py --cpu-seconds 0 --steps 10 | tail -1 | cut -c1-100
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r2_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r2_pytest.log
+timeout 200 python bench.py 2>&1 | tail -1
+timeout 100 python bench.py --workload 1ppe --batch 65536 --cpu-seconds 0 2>&1 | tail -1 | cut -c1-200
