@@ -6,11 +6,12 @@ import os
 import re
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
 
-from conftest import CASES, GOLDEN, case_paths
+from conftest import CASES, GOLDEN, ROOT, case_paths
 
 
 def test_library_exports_every_declared_symbol(pkg):
@@ -368,3 +369,73 @@ def test_dfire_tile_layout(pkg, orc, table):
     geometric = pkg.spatial_tile_order(xyz)
     assert partnered(order, perm) > partnered(geometric, np.arange(169)) + 0.15
     assert partnered(order, perm) > 0.6
+
+
+def test_dfire_tables_equal_reference():
+    """tools/check_dfire_tables.py: the reference's r3_to_numerical / ATOMNUMBER / ATOMRES / DIST_TO_BINS
+    literals (src/dfire.rs:18-101) against the oracle's restated tables and the product's closed-form
+    host model builder, over every (residue, atom) key.  Needs the reference tree: build container only."""
+    if not os.path.exists("/root/reference/src/dfire.rs"):
+        pytest.skip("reference tree not present (GPU box)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dfire_tables.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "equal the reference" in r.stdout
+
+
+@pytest.mark.parametrize("cells", [1, 2])
+def test_packed_kernel_cell_lut_decides_like_the_reference(pkg, orc, cells):
+    """The default DFIRE kernel tests pairs in f32: D' = cells * 4 d2 + 1/2 with an error below eps/2
+    (eps carries a factor 2), cell = floor(D').  Whatever f32 value a true f64 distance can turn into,
+    the LUT word of its cell must give the reference's answer -- bin (src/dfire.rs:336-337), cutoff
+    (:334), interface (:339) -- or send the pair to the exact f64 path.  This replays the kernel's
+    decision logic (dfire_packed.hip, "lean" cells) on the host for dense samples around every step."""
+    words, eps = pkg.dfire_packed_lut(cells, 256.0)
+    _, steps, iface = pkg.dfire_bin_lut()
+    assert 0.0 < eps * cells < 0.2
+    MISS, SLOW = 0x00800000, 0x40000000
+
+    def term(b):
+        return 8 * (b + 12 * (b >> 2))
+
+    def reference(d4):
+        d2 = d4 / 4.0
+        return orc.dfire_bin(d2) if d2 <= 225.0 else None
+
+    rng = np.random.default_rng(11)
+    cand = list(rng.uniform(0.0, 1100.0, 30000))
+    for s in list(steps[1:]) + [iface]:
+        cand += [4.0 * s + d for d in (-0.3, -0.1, -2 * eps, -eps, -eps / 2, -1e-9, 0.0, 1e-9, eps / 2, eps, 2 * eps, 0.1, 0.3)]
+    exact = lean = plain = 0
+    for d4 in cand:
+        if d4 < 0.0:
+            continue
+        want = reference(d4)
+        for err in (-eps / 2, -eps / 4, 0.0, eps / 4, eps / 2):
+            dp = float(np.float32(cells * (d4 + err) + 0.5))
+            if dp < 0.0:
+                continue
+            c = min(int(dp), 1024 * cells)
+            w = int(words[c])
+            if w < MISS:
+                plain += 1
+                assert want is not None and w == term(want) and not d4 / 4.0 <= iface, (d4, err, hex(w))
+            elif w == MISS:
+                assert want is None, (d4, err)
+            else:
+                assert w & SLOW
+                code = (w >> 24) & 0x1F
+                delta = (dp - int(dp)) - 0.5
+                if code in (0x01, 0x11) and abs(delta) > eps * cells:      # lean: decided in f32
+                    lean += 1
+                    t = (w & 0xFFF) + (0 if delta < 0.0 else (w >> 12) & 0xFFF)
+                    if t == term(21):                   # the zero slot behind the last bin: beyond the cutoff
+                        assert want is None, (d4, err)
+                    else:
+                        assert want is not None and t == term(want), (d4, err, hex(w))
+                        assert (d4 / 4.0 <= iface) == (code == 0x11), (d4, err)
+                else:
+                    exact += 1                          # exact f64 path: right by construction
+    assert plain > 100000 and lean > 100 and exact > 10
+    # the cells the pair loop handles without any branch hold one bin each, over their whole interval
+    flagged = int(((words >> 30) & 1).sum())
+    assert flagged < 40 * cells + 10
