@@ -81,6 +81,13 @@ void Gso::run(uint32_t steps) {
     const char *env = std::getenv("LIGHTDOCK_GSO_GRAPH");
     const bool want_graph = !(env && std::strcmp(env, "0") == 0);
     if (want_graph && steps >= 6 && !(scorer_.use_anm() && scorer_.anm_rec() > 0)) {
+        // The captured launches carry the addresses of the scorer's shared workspaces.  Another user
+        // of the same scorer (a larger pose batch, a larger GSO) may have reallocated them since.
+        scorer_.prepare_batch(n_swarms_ * n_glowworms_);
+        if (graph_exec_ && graph_generation_ != scorer_.workspace_generation()) {
+            (void)hipGraphExecDestroy(graph_exec_);
+            graph_exec_ = nullptr;
+        }
         if (!graph_exec_) {
             step();  // eager once: every workspace reaches its final size
             steps--;
@@ -102,6 +109,7 @@ void Gso::run(uint32_t steps) {
             scorer_.set_capturing(false);
             if (ok && graph && hipGraphInstantiate(&graph_exec_, graph, nullptr, nullptr, 0) != hipSuccess) graph_exec_ = nullptr;
             graph_cur_ = cur_;  // the captured pair of steps starts from this pose buffer
+            graph_generation_ = scorer_.workspace_generation();
             if (graph) (void)hipGraphDestroy(graph);
             (void)hipGetLastError();
         }

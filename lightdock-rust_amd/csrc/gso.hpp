@@ -55,6 +55,7 @@ class Gso {
     unsigned long long *evals_ = nullptr;
     hipGraphExec_t graph_exec_ = nullptr;  // two captured steps (even + odd pose buffer)
     int graph_cur_ = 0;
+    uint64_t graph_generation_ = 0;  // scorer workspace generation the graph was captured against
 };
 
 }  // namespace ld

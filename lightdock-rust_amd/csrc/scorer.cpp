@@ -24,6 +24,7 @@ void *DeviceArena::alloc_bytes(size_t bytes) {
 }
 void DeviceBuffer::reserve(size_t want) {
     if (want <= bytes) return;
+    generation++;  // the old block is gone: whoever baked its address (a captured hipGraph) must notice
     release();
     size_t grow = want + want / 4 + 256;
     hip_check(hipMalloc(&ptr, grow), "hipMalloc(workspace)");
@@ -641,6 +642,11 @@ Scorer::~Scorer() {
     ws_exact_.release();
     ws_poses_.release();
     ws_energies_.release();
+}
+
+uint64_t Scorer::workspace_generation() const {
+    return ws_partial_.generation + ws_flags_.generation + ws_counts_.generation + ws_tested_.generation + ws_exact_.generation +
+           ws_rec_atoms_.generation + ws_rec_sub_.generation + ws_rec_tile_.generation + ws_rec_pairs_.generation + ws_rec_xyz_.generation;
 }
 
 void Scorer::reserve_workspace(size_t n_poses, bool counts) {

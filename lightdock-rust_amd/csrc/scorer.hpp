@@ -44,6 +44,7 @@ class DeviceArena {
 struct DeviceBuffer {
     void *ptr = nullptr;
     size_t bytes = 0;
+    uint64_t generation = 0;  // bumped whenever the block is reallocated
     void reserve(size_t want);
     void release();
 };
@@ -84,6 +85,9 @@ class Scorer {
     void set_capturing(bool on) { capturing_ = on; }
     // make sure no allocation happens in the next energy_batch_device call of this size
     void prepare_batch(size_t n_poses) { reserve_workspace(n_poses, false); }
+    // Changes whenever a workspace block of this scorer was reallocated (a larger batch came by): a
+    // hipGraph captured before that replays kernels into freed memory and must be captured again.
+    uint64_t workspace_generation() const;
 
     // Enqueue K1 for n poses already in HBM.  active / pair_counts may be null.
     void energy_batch_device(size_t n, const double *d_poses, size_t stride, const uint8_t *d_active,

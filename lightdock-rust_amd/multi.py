@@ -74,6 +74,19 @@ def timed_region(fn, dist, sync=None):
     return elapsed
 
 
+def sum_over_ranks(value, dist):
+    """Sum of one number over the ranks (timing / evaluation counts only; never pose data)."""
+    rank, size = world(dist)
+    if size == 1:
+        return value
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
 def run_swarms(make_gso, n_swarms, steps, dist, summarize):
     """Run `n_swarms` independent swarms sharded over the ranks.
 

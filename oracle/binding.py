@@ -51,6 +51,7 @@ def lib():
     L.orc_scorer_free.argtypes = [vp]
     L.orc_scorer_energy.argtypes = [vp, vp, vp, vp, vp]
     L.orc_scorer_energy_ex.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.orc_scorer_energy_rows_mt.argtypes = [vp, vp, sz, sz, C.c_int, vp]
     L.orc_scorer_num_atoms.restype = sz
     L.orc_scorer_num_atoms.argtypes = [vp, C.c_int]
     for name in ("orc_scorer_coordinates", "orc_scorer_dfire_types", "orc_scorer_ele_charges", "orc_scorer_vdw_charges",
@@ -241,6 +242,14 @@ class Scorer:
 
     def energy_rows(self, rows):
         return np.array([self.energy_row(r) for r in np.asarray(rows)])
+
+    def energy_rows_mt(self, rows, threads):
+        """All rows on `threads` host threads inside the library (the bench's CPU baseline)."""
+        rows = _f64(rows)
+        out = np.empty(rows.shape[0])
+        if lib().orc_scorer_energy_rows_mt(self._h, _p(rows), rows.shape[0], rows.shape[1], int(threads), _p(out)) != 0:
+            raise ValueError("orc_scorer_energy_rows_mt: bad arguments")
+        return out
 
     def energy_ex_row(self, row):
         t, q, rn, ln = self._split(row)

@@ -1137,3 +1137,43 @@ double *orc_read_npy_f64(const char *path, size_t *len) { /* bin:221-252 (npyz 0
     *len = count;
     return data;
 }
+
+/* --- bench baseline: many poses on several host threads --------------------------------------
+ * What `ant_thony.py --cores N` does for the reference (example/1czy/execution.sh:24): N
+ * independent single-threaded evaluations side by side.  Thread k takes rows k, k+threads, ...
+ * Row layout = the .dat pose row [t(3) q(4) rec_nm lig_nm]; each evaluation is orc_scorer_energy. */
+#include <pthread.h>
+typedef struct {
+    const orc_scorer *s;
+    const double *rows;
+    size_t n, stride;
+    int first, step, anm_rec, anm_lig;
+    double *out;
+} rows_job_t;
+static void *rows_worker(void *arg) {
+    rows_job_t *j = (rows_job_t *)arg;
+    for (size_t i = (size_t)j->first; i < j->n; i += (size_t)j->step) {
+        const double *r = j->rows + i * j->stride;
+        j->out[i] = orc_scorer_energy(j->s, r, r + 3, j->anm_rec ? r + 7 : NULL, j->anm_lig ? r + 7 + j->anm_rec : NULL);
+    }
+    return NULL;
+}
+int orc_scorer_energy_rows_mt(const orc_scorer *s, const double *rows, size_t n, size_t stride, int threads, double *out) {
+    if (!s || !rows || !out || threads < 1 || threads > 1024) return -1;
+    const int anm_rec = s->use_anm ? s->receptor.num_anm : 0, anm_lig = s->use_anm ? s->ligand.num_anm : 0;
+    if (stride < (size_t)(7 + anm_rec + anm_lig)) return -1;
+    pthread_t *th = (pthread_t *)malloc((size_t)threads * sizeof *th);
+    rows_job_t *jobs = (rows_job_t *)malloc((size_t)threads * sizeof *jobs);
+    if (!th || !jobs) { free(th); free(jobs); return -1; }
+    int started = 0;
+    for (int k = 0; k < threads; k++) {
+        jobs[k] = (rows_job_t){s, rows, n, stride, k, threads, anm_rec, anm_lig, out};
+        if (pthread_create(&th[k], NULL, rows_worker, &jobs[k]) != 0) break;
+        started++;
+    }
+    for (int k = started; k < threads; k++) rows_worker(&jobs[k]); /* could not start: do its share here */
+    for (int k = 0; k < started; k++) pthread_join(th[k], NULL);
+    free(th);
+    free(jobs);
+    return 0;
+}

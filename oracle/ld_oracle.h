@@ -94,6 +94,11 @@ double orc_scorer_energy(const orc_scorer *s, const double t[3], const double q[
 double orc_scorer_energy_ex(const orc_scorer *s, const double t[3], const double q[4],
                             const double *rec_nm, const double *lig_nm, double stats[8]);
 
+/* n pose rows ([t q rec_nm lig_nm], `stride` doubles apart) on `threads` host threads, thread k taking
+ * rows k, k+threads, ...: the stand-in for `ant_thony.py --cores N` (example/1czy/execution.sh:24)
+ * that bench.py times as the CPU baseline.  Returns 0, or -1 on bad arguments. */
+int orc_scorer_energy_rows_mt(const orc_scorer *s, const double *rows, size_t n, size_t stride, int threads, double *out);
+
 /* model introspection, side: 0 receptor, 1 ligand */
 size_t orc_scorer_num_atoms(const orc_scorer *s, int side);
 const double *orc_scorer_coordinates(const orc_scorer *s, int side); /* n*3 AoS */

@@ -56,6 +56,8 @@ def _worker(rank, world_size, port, out_path):
         holder["res"] = multi.run_swarms(Batch, 5, 2, dist, summarize)
 
     elapsed = multi.timed_region(job, dist)
+    # bench.py's whole-job evaluation count: a plain sum over the ranks
+    assert multi.sum_over_ranks(10 * (rank + 1), dist) == 10 * sum(range(1, world_size + 1))
     if rank == 0:
         np.save(out_path, np.array([elapsed] + [r[1] for r in holder["res"]]))
         assert [r[0] for r in holder["res"]] == list(range(5))
