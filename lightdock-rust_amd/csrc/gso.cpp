@@ -11,6 +11,19 @@
 
 namespace ld {
 
+// rand_core 0.5 SeedableRng::seed_from_u64 (what StdRng::seed_from_u64 of src/lib.rs:38 runs): PCG32
+// expansion of the u64 into the eight ChaCha key words
+void stdrng_key_from_seed(uint64_t seed, uint32_t key[8]) {
+    uint64_t state = seed;
+    for (int i = 0; i < 8; i++) {
+        state = state * 6364136223846793005ULL + 11634580027462260723ULL;
+        const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+        const uint32_t rot = (uint32_t)(state >> 59);
+        key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+    }
+}
+
+
 Gso::Gso(Scorer &scorer, size_t n_swarms, size_t n_glowworms, const double *positions, const uint64_t *seeds)
     : scorer_(scorer), n_swarms_(n_swarms), n_glowworms_(n_glowworms), pose_len_(scorer.pose_len()) {
     if (n_swarms == 0 || n_glowworms == 0) throw Error(LD_ERR_INVALID, "ld_gso_create: empty swarm");

@@ -7,6 +7,7 @@
 // 64x64 blocks of pairs can be discarded with one box-distance test.
 #pragma once
 
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 

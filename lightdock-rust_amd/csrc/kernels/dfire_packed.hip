@@ -628,18 +628,6 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_MIN_BLOCKS) void dfire
 
 }  // namespace
 
-double dfire_f32_error_bound(double ubound, int cells_per_unit) {
-    // In record units (D' = cells_per_unit * 4 d2 + 1/2).  Records: |fl32(u) - u| <= 2^-25 U for
-    // |u| < U = a power of two.  Differences of pairs in range (4 d2 < 1100): the exact difference
-    // of two records is within 2 e_u of the true one and below 128, so its rounding adds at most
-    // 2^-25 * 128.  Then the squares and the three fma roundings (results below 4096).
-    const double e_u = std::ldexp(ubound, -25);
-    const double e_d = 2.0 * e_u + std::ldexp(128.0, -25);
-    const double span = std::sqrt(3.0 * 1100.0 * cells_per_unit);
-    const double eps = 2.0 * e_d * span + 3.0 * e_d * e_d + 3.0 * std::ldexp(4096.0, -25);
-    return 2.0 * eps / cells_per_unit;  // twice the bound, in units of 4 d2
-}
-
 size_t packed_kernel_lds_bytes(int cells_per_unit) {
     return (size_t)kPackedLutCells * cells_per_unit * sizeof(uint32_t) + kDfireSteps * sizeof(double) +
            (size_t)kPackedWaves * (72 * sizeof(LigRecord) + 32 * sizeof(PackedRecPair) + kPackedQueue * 4) + kPackedWaves * 24;

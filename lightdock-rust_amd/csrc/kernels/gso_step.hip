@@ -236,14 +236,4 @@ hipError_t launch_gso_step(const GsoLaunch &g, hipStream_t stream) {
     return hipGetLastError();
 }
 
-void stdrng_key_from_seed(uint64_t seed, uint32_t key[8]) {
-    uint64_t state = seed;
-    for (int i = 0; i < 8; i++) {
-        state = state * 6364136223846793005ULL + 11634580027462260723ULL;
-        const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
-        const uint32_t rot = (uint32_t)(state >> 59);
-        key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
-    }
-}
-
 }  // namespace ld

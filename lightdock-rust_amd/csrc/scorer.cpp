@@ -442,6 +442,18 @@ void Scorer::build_tiled(const ld_scorer_desc &desc) {
     }
 }
 
+double dfire_f32_error_bound(double ubound, int cells_per_unit) {
+    // In record units (D' = cells_per_unit * 4 d2 + 1/2).  Records: |fl32(u) - u| <= 2^-25 U for
+    // |u| < U = a power of two.  Differences of pairs in range (4 d2 < 1100): the exact difference
+    // of two records is within 2 e_u of the true one and below 128, so its rounding adds at most
+    // 2^-25 * 128.  Then the squares and the three fma roundings (results below 4096).
+    const double e_u = std::ldexp(ubound, -25);
+    const double e_d = 2.0 * e_u + std::ldexp(128.0, -25);
+    const double span = std::sqrt(3.0 * 1100.0 * cells_per_unit);
+    const double eps = 2.0 * e_d * span + 3.0 * e_d * e_d + 3.0 * std::ldexp(4096.0, -25);
+    return 2.0 * eps / cells_per_unit;  // twice the bound, in units of 4 d2
+}
+
 // The cell LUT of the packed DFIRE kernel (kernels/dfire_packed.hpp) for `sc` cells per unit of
 // 4 d2 and an f32 distance error of at most `eps` (units of 4 d2).
 std::vector<uint32_t> build_packed_lut(int sc, double eps) {

@@ -7,7 +7,10 @@ method` process per swarm), done as ONE batched GSO per GPU.
 Run it under `python -m torch.distributed.run --nproc-per-node N ...` to shard the swarms over
 N GPUs (rank r takes swarms r, r+N, ...; no collective touches the data path).  Path rules
 follow src/bin/lightdock-rust.rs:158-333: PDBs next to setup.json with the "lightdock_" prefix;
-swarm_<i>/, rec_nm.npy, lig_nm.npy and $LIGHTDOCK_DATA|data/DCparams relative to the CWD.
+swarm_<i>/, rec_nm.npy, lig_nm.npy and $LIGHTDOCK_DATA|data/DCparams relative to the CWD.  Where the
+flattened rec_nm.npy / lig_nm.npy (lgd_flatten.py, example/1czy/execution.sh:10-11) are missing, the
+(modes, atoms, 3) files lightdock3_setup.py writes -- lightdock_rec.nm.npy / lightdock_lig.nm.npy, in the
+CWD or next to setup.json -- are read instead: same numbers, same order.
 """
 import argparse
 import json
@@ -37,6 +40,15 @@ def read_positions(path, pose_len, use_anm):
     return rows[:, :pose_len]
 
 
+def load_nmodes(side, sim):
+    """rec_nm.npy / lig_nm.npy of the CWD (src/bin/lightdock-rust.rs:231-232), else the unflattened
+    lightdock_<side>.nm.npy; C-order flattening of (modes, atoms, 3) is what lgd_flatten.py does."""
+    for path in ("%s_nm.npy" % side, "lightdock_%s.nm.npy" % side, os.path.join(sim, "lightdock_%s.nm.npy" % side)):
+        if os.path.exists(path):
+            return np.ascontiguousarray(np.load(path), dtype=np.float64).reshape(-1)
+    raise FileNotFoundError("neither %s_nm.npy nor lightdock_%s.nm.npy found" % (side, side))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("setup")
@@ -54,6 +66,9 @@ def main(argv=None):
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if os.environ.get("LIGHTDOCK_DEVICE") is not None:      # e.g. several ranks on one GPU for a dry run
         local = int(os.environ["LIGHTDOCK_DEVICE"])
+    n_dev = pkg.device_count()
+    if n_dev > 0 and local >= n_dev:       # ranks that each see only their own GPU (HIP_VISIBLE_DEVICES per rank)
+        local = local % n_dev
     pkg.init(local)
     setup = json.load(open(args.setup))
     sim = os.path.dirname(os.path.abspath(args.setup))
@@ -66,9 +81,9 @@ def main(argv=None):
             kw[side + "_active"], kw[side + "_passive"] = r["active"], r["passive"]
     if use_anm:
         if kw["rec_num_anm"] > 0:
-            kw["rec_nmodes"] = np.load("rec_nm.npy")
+            kw["rec_nmodes"] = load_nmodes("rec", sim)
         if kw["lig_num_anm"] > 0:
-            kw["lig_nmodes"] = np.load("lig_nm.npy")
+            kw["lig_nmodes"] = load_nmodes("lig", sim)
     if method == "dfire":
         kw["potential"] = pkg.load_dcparams(os.path.join(os.environ.get("LIGHTDOCK_DATA", "data"), "DCparams"))
     scorer = pkg.Scorer.from_pdb(method, os.path.join(sim, "lightdock_" + setup["receptor_pdb"]),

@@ -182,6 +182,16 @@ static int opt_restraints(const jval *o, const char *key, int *present, char ***
     return 0;
 }
 
+static void setup_free(setup_t *s) {
+    char **lists[4] = {s->rec_active, s->rec_passive, s->lig_active, s->lig_passive};
+    int ns[4] = {s->n_rec_active, s->n_rec_passive, s->n_lig_active, s->n_lig_passive};
+    for (int w = 0; w < 4; w++) {
+        for (int k = 0; lists[w] && k < ns[w]; k++) free(lists[w][k]);
+        free(lists[w]);
+    }
+    memset(s, 0, sizeof *s);
+}
+
 static int read_setup(const char *path, setup_t *s, char *err, size_t cap, int *missing_key) {
     memset(s, 0, sizeof *s);
     FILE *f = fopen(path, "rb");
@@ -292,8 +302,13 @@ int orc_cli_main(int argc, char **argv) {
     if (read_setup(setup_filename, &setup, err, sizeof err, &missing_key) != 0) { /* bin:118-129 */
         rust_debug_str(setup_filename, dbg, sizeof dbg);
         fprintf(stderr, "Error reading setup file [%s]: \"%s\"\n", dbg, err);
+        setup_free(&setup);
         return 0;
     }
+    int code = 0;
+    double *potential = NULL, *positions = NULL, *rec_nm = NULL, *lig_nm = NULL;
+    orc_scorer *scorer = NULL;
+    orc_gso *gso = NULL;
     /* simulation path = parent of the setup file, bin:131 */
     char simulation_path[2048];
     snprintf(simulation_path, sizeof simulation_path, "%s", setup_filename);
@@ -306,7 +321,7 @@ int orc_cli_main(int argc, char **argv) {
     int swarm_id;
     if (parse_swarm_id(swarm_filename, &swarm_id) != 0) {
         fprintf(stderr, "Could not parse swarm from swarm filename\n");
-        return 101;
+        { code = 101; goto done; }
     }
     printf("Swarm ID %d\n", swarm_id);
     char swarm_directory[64];
@@ -314,13 +329,13 @@ int orc_cli_main(int argc, char **argv) {
     struct stat sb;
     if (stat(swarm_directory, &sb) != 0 || !S_ISDIR(sb.st_mode)) { /* bin:176-185 */
         fprintf(stderr, "Output directory does not exist for swarm %d, creating it\n", swarm_id);
-        if (mkdir(swarm_directory, 0777) != 0) { fprintf(stderr, "Error creating directory\n"); return 101; }
+        if (mkdir(swarm_directory, 0777) != 0) { fprintf(stderr, "Error creating directory\n"); { code = 101; goto done; } }
     }
     rust_debug_str(swarm_directory, dbg, sizeof dbg);
     printf("Writing to swarm dir %s\n", dbg);
     int n_rows = 0, row_len = 0;
-    double *positions = orc_parse_positions(swarm_filename, &n_rows, &row_len);
-    if (!positions) { fprintf(stderr, "%s\n", orc_last_error()); return 101; }
+    positions = orc_parse_positions(swarm_filename, &n_rows, &row_len);
+    if (!positions) { fprintf(stderr, "%s\n", orc_last_error()); { code = 101; goto done; } }
 
     char receptor_filename[4096], ligand_filename[4096];
     if (simulation_path[0] == 0) {
@@ -332,44 +347,46 @@ int orc_cli_main(int argc, char **argv) {
     }
     /* pdbtbx::open(..).unwrap() happens here, before the ANM files are read (bin:190-214) */
     printf("Reading receptor input structure: %s\n", receptor_filename);
-    { FILE *t = fopen(receptor_filename, "r"); if (!t) { fflush(stdout); fprintf(stderr, "cannot open PDB file %s\n", receptor_filename); return 101; } fclose(t); }
+    { FILE *t = fopen(receptor_filename, "r"); if (!t) { fflush(stdout); fprintf(stderr, "cannot open PDB file %s\n", receptor_filename); { code = 101; goto done; } } fclose(t); }
     printf("Reading ligand input structure: %s\n", ligand_filename);
-    { FILE *t = fopen(ligand_filename, "r"); if (!t) { fflush(stdout); fprintf(stderr, "cannot open PDB file %s\n", ligand_filename); return 101; } fclose(t); }
+    { FILE *t = fopen(ligand_filename, "r"); if (!t) { fflush(stdout); fprintf(stderr, "cannot open PDB file %s\n", ligand_filename); { code = 101; goto done; } } fclose(t); }
 
-    double *rec_nm = NULL, *lig_nm = NULL;
+    (void)0;
     size_t rec_nm_len = 0, lig_nm_len = 0;
     if (setup.use_anm) { /* bin:216-254 */
-        if (setup.anm_rec > 0 && !(rec_nm = orc_read_npy_f64("rec_nm.npy", &rec_nm_len))) { fprintf(stderr, "%s\n", orc_last_error()); return 101; }
-        if (setup.anm_lig > 0 && !(lig_nm = orc_read_npy_f64("lig_nm.npy", &lig_nm_len))) { fprintf(stderr, "%s\n", orc_last_error()); return 101; }
+        if (setup.anm_rec > 0 && !(rec_nm = orc_read_npy_f64("rec_nm.npy", &rec_nm_len))) { fprintf(stderr, "%s\n", orc_last_error()); { code = 101; goto done; } }
+        if (setup.anm_lig > 0 && !(lig_nm = orc_read_npy_f64("lig_nm.npy", &lig_nm_len))) { fprintf(stderr, "%s\n", orc_last_error()); { code = 101; goto done; } }
     }
-    if (missing_key) { fprintf(stderr, "restraints map lacks \"active\"/\"passive\"\n"); return 101; }
+    if (missing_key) { fprintf(stderr, "restraints map lacks \"active\"/\"passive\"\n"); { code = 101; goto done; } }
 
     printf("Loading %s scoring function\n", method_dbg);
-    double *potential = NULL;
+    (void)0;
     if (method == ORC_METHOD_DFIRE) { /* dfire.rs:236-257 */
         const char *data = getenv("LIGHTDOCK_DATA");
         char ppath[4096];
         snprintf(ppath, sizeof ppath, "%s/DCparams", data ? data : "data");
         potential = (double *)malloc(ORC_DFIRE_TABLE_LEN * sizeof(double));
-        if (orc_load_dcparams(ppath, potential) != 0) { fprintf(stderr, "%s\n", orc_last_error()); return 101; }
+        if (orc_load_dcparams(ppath, potential) != 0) { fprintf(stderr, "%s\n", orc_last_error()); { code = 101; goto done; } }
     }
-    orc_scorer *scorer = orc_scorer_new(method, receptor_filename, ligand_filename,
+    scorer = orc_scorer_new(method, receptor_filename, ligand_filename,
                                         (const char *const *)setup.rec_active, setup.n_rec_active,
                                         (const char *const *)setup.rec_passive, setup.n_rec_passive, rec_nm, rec_nm_len,
                                         (int)setup.anm_rec, (const char *const *)setup.lig_active, setup.n_lig_active,
                                         (const char *const *)setup.lig_passive, setup.n_lig_passive, lig_nm, lig_nm_len,
                                         (int)setup.anm_lig, setup.use_anm, potential);
-    if (!scorer) { fprintf(stderr, "%s\n", orc_last_error()); return 101; }
+    if (!scorer) { fprintf(stderr, "%s\n", orc_last_error()); { code = 101; goto done; } }
 
     printf("Creating GSO with %d glowworms\n", n_rows);
-    orc_gso *gso = orc_gso_new(positions, n_rows, row_len, seed, scorer, setup.use_anm, (int)setup.anm_rec, (int)setup.anm_lig);
-    if (!gso) { fprintf(stderr, "%s\n", orc_last_error()); return 101; }
+    gso = orc_gso_new(positions, n_rows, row_len, seed, scorer, setup.use_anm, (int)setup.anm_rec, (int)setup.anm_lig);
+    if (!gso) { fprintf(stderr, "%s\n", orc_last_error()); { code = 101; goto done; } }
     printf("Starting optimization (%d steps)\n", steps);
     fflush(stdout);
     int rc = orc_gso_run(gso, steps, swarm_directory);
-    if (rc != 0) { fprintf(stderr, "%s\n", orc_last_error()); return 101; }
+    if (rc != 0) { fprintf(stderr, "%s\n", orc_last_error()); { code = 101; goto done; } }
+done:
     orc_gso_free(gso);
     orc_scorer_free(scorer);
     free(potential); free(positions); free(rec_nm); free(lig_nm);
-    return 0;
+    setup_free(&setup);
+    return code;
 }

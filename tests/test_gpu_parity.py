@@ -361,6 +361,27 @@ def test_gso_run_graph_replay_equals_stepping(pkg, scorers, orc):
     assert a.num_evals == b.num_evals == ref.num_evals
 
 
+def test_gso_graph_survives_workspace_reallocation(pkg, scorers, orc):
+    """The captured hipGraph carries the addresses of the scorer's shared workspaces.  A larger batch
+    on the same scorer reallocates them between two ld_gso_run calls: the next run must capture
+    again instead of replaying launches into freed memory."""
+    hip, cpu = scorers("1ppe")
+    poses = case_positions("1ppe", orc)
+    a, b = pkg.GSO(hip, poses), pkg.GSO(hip, poses)
+    a.run(12)                                             # captures at 200 poses
+    big = np.tile(poses, (40, 1))
+    hip.energy_batch(big)                                 # 8000 poses: every workspace grows
+    big_gso = pkg.GSO(hip, np.stack([poses] * 24))        # and a larger GSO on the same scorer
+    big_gso.run(8)
+    a.run(12)
+    for _ in range(24):
+        b.step()
+    sa, sb = a.read(0), b.read(0)
+    for k in ("poses", "luciferin", "vision_range", "scoring", "n_neighbors", "target", "moved"):
+        assert np.array_equal(sa[k], sb[k]), k
+    assert a.num_evals == b.num_evals
+
+
 def _write_pdb(path, atoms):
     """atoms: (name, resname, chain, resseq, x, y, z)"""
     with open(path, "w") as f:
@@ -672,6 +693,46 @@ def test_multi_swarm_launcher(pkg, tmp_path):
         for step in (1, 10):
             name = os.path.join("swarm_%d" % s, "gso_%d.out" % step)
             assert open(run2 / name).read() == open(run / name).read()
+
+
+@pytest.mark.timeout(600)
+def test_launcher_on_the_reference_multi_swarm_example_1czy(pkg, orc, tmp_path):
+    """example/1czy is the reference's only real multi-swarm run (example/1czy/execution.sh:20-24: ten
+    `lightdock-rust setup.json init/initial_positions_<i>.dat 100 dfire` tasks under ant_thony.py):
+    DFIRE + receptor/ligand ANM + an active receptor restraint, 1281 x 53 atoms.  launch.py does the ten
+    swarms as one batched GSO; every gso_*.out must equal what the CPU oracle CLI writes for the
+    same swarm to print precision, neighbour counts exactly (synthetic DCparams: the real table is
+    not in the reference mount).
+    The ANM modes are read from lightdock_{rec,lig}.nm.npy as lightdock3_setup.py leaves them."""
+    src = os.path.join(GOLDEN, "1czy")
+    run = tmp_path / "run"
+    (run / "data").mkdir(parents=True)
+    pkg.synth.write_dcparams(str(run / "data" / "DCparams"))
+    for f in ("lightdock_rec.nm.npy", "lightdock_lig.nm.npy"):      # no flattened rec_nm.npy / lig_nm.npy here
+        shutil.copy(os.path.join(src, f), run)
+    launcher = os.path.join(os.path.dirname(pkg.__file__), "launch.py")
+    steps = 20
+    r = subprocess.run([os.sys.executable, launcher, os.path.join(src, "setup.json"), str(steps), "dfire", "--swarms", "0-9",
+                        "--init-dir", os.path.join(src, "init")], cwd=run, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "10 swarms" in r.stdout
+    ref = tmp_path / "ref"
+    (ref / "data").mkdir(parents=True)
+    shutil.copy(run / "data" / "DCparams", ref / "data" / "DCparams")
+    for f in ("rec_nm.npy", "lig_nm.npy"):                           # the reference's own flattened files
+        shutil.copy(os.path.join(src, f), ref)
+    for s in (0, 3, 9):
+        r = subprocess.run([orc.CLI_PATH, os.path.join(src, "setup.json"), os.path.join(src, "init", "initial_positions_%d.dat" % s),
+                            str(steps), "dfire"], cwd=ref, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for step in (1, 10, 20):
+            name = os.path.join("swarm_%d" % s, "gso_%d.out" % step)
+            a, b = parse_gso(str(run / name)), parse_gso(str(ref / name))
+            assert np.array_equal(a[2], b[2]), name                    # neighbour counts
+            for x, y in zip(a, b):
+                assert np.allclose(x, y, rtol=0, atol=2e-7), name      # print precision (7 / 8 decimals)
+    for s in range(10):
+        assert sorted(os.listdir(run / ("swarm_%d" % s))) == ["gso_1.out", "gso_10.out", "gso_20.out"]
 
 
 def test_block_count_diagnostics(pkg, scorers, orc):

@@ -173,6 +173,45 @@ def test_real_dcparams_goldens(orc, real_dcparams):
         assert np.all(np.abs(got - want[:40]) <= 1.01e-8 + 1e-9 * np.abs(want[:40])), name
 
 
+def test_oracle_cli_on_the_multi_swarm_example_1czy(orc, pkg, tmp_path):
+    """example/1czy (ten swarms, DFIRE + ANM + an active receptor restraint): the oracle CLI runs two of
+    its swarms from init/initial_positions_<i>.dat; the step-1 file must carry the start poses moved once
+    and the energies of the start poses, which the scorer API gives too.  With the real DCparams
+    ($LIGHTDOCK_DATA) the files must also equal the reference's own swarm_<i>/gso_1.out."""
+    src = os.path.join(GOLDEN, "1czy")
+    (tmp_path / "data").mkdir()
+    real = os.environ.get("LIGHTDOCK_DATA")
+    real = os.path.join(real, "DCparams") if real else None
+    if real and os.path.exists(real):
+        shutil.copy(real, tmp_path / "data" / "DCparams")
+        table = orc.load_dcparams(real)
+    else:
+        real = None
+        pkg.synth.write_dcparams(str(tmp_path / "data" / "DCparams"))
+        table = pkg.synth.dcparams()
+    for f in ("rec_nm.npy", "lig_nm.npy"):
+        shutil.copy(os.path.join(src, f), tmp_path)
+    scorer = orc.Scorer("dfire", os.path.join(src, "lightdock_1czy_protein.pdb"), os.path.join(src, "lightdock_1czy_peptide.pdb"),
+                        rec_active=["A.SER.467"], rec_nmodes=np.load(os.path.join(src, "rec_nm.npy")), rec_num_anm=10,
+                        lig_nmodes=np.load(os.path.join(src, "lig_nm.npy")), lig_num_anm=10, use_anm=True, potential=table)
+    assert scorer.num_atoms(0) == 1281 and scorer.num_atoms(1) == 53
+    from conftest import parse_gso
+    for s in (0, 7):
+        init = os.path.join(src, "init", "initial_positions_%d.dat" % s)
+        r = subprocess.run([orc.CLI_PATH, os.path.join(src, "setup.json"), init, "1", "dfire"], cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = parse_gso(str(tmp_path / ("swarm_%d" % s) / "gso_1.out"))
+        poses = orc.parse_positions(init)
+        assert poses.shape == (200, 27)
+        want = scorer.energy_rows(poses[:25])
+        assert np.all(np.abs(got[4][:25] - want) <= 0.51e-8 + 1e-11 * np.abs(want))
+        if real:
+            ref = parse_gso(os.path.join(src, "swarm_%d" % s, "gso_1.out"))
+            assert np.array_equal(got[2], ref[2])
+            for x, y in zip(got, ref):
+                assert np.allclose(x, y, rtol=0, atol=2e-7)
+
+
 def test_pydock_known_answer_and_generic_fallback(orc, tmp_path):
     """src/pydock.rs:553-587: same golden as DNA; src/pydock.rs:332-345: unknown atoms are typed
     by the first letter of their name, H1/H2/H3 still only fall back to "<res>-H"."""
