@@ -47,6 +47,7 @@ extern "C" {
     fn ld_gso_destroy(g: *mut c_void);
     fn ld_gso_run(g: *mut c_void, steps: u32) -> c_int;
     fn ld_gso_save(g: *mut c_void, swarm: usize, step: u32, dir: *const c_char) -> c_int;
+    fn ld_gso_save_many(g: *mut c_void, n: usize, swarms: *const usize, dirs: *const *const c_char, step: u32) -> c_int;
 }
 
 fn last_error() -> String {
@@ -90,6 +91,11 @@ impl ModelArrays {
     }
 }
 
+/// Thread-compatibility: `ld_scorer_energy` reuses the handle's device workspaces and its stream, so a
+/// handle serves ONE thread at a time.  The raw pointer field makes `HipScore` neither `Send` nor
+/// `Sync` (which the compiler then enforces): exactly what the reference needs, whose `Score` trait has
+/// no `Send + Sync` bound and whose binary scores on one worker thread (src/bin/lightdock-rust.rs:79-85).
+/// A multi-threaded host creates one `HipScore` per thread (one per GPU in practice).
 pub struct HipScore {
     handle: *mut c_void,
 }
@@ -174,10 +180,18 @@ impl<'a> HipGso<'a> {
             assert_eq!(unsafe { ld_gso_run(self.handle, next - done) }, 0, "{}", last_error());
             done = next;
             if done % 10 == 0 || done == 1 {
-                for (swarm, dir) in output_directories.iter().enumerate() {
-                    let c = CString::new(dir.as_str()).unwrap();
-                    let rc = unsafe { ld_gso_save(self.handle, swarm, done, c.as_ptr()) };
-                    if rc != 0 {
+                // one device read for all swarms, files written by threads (ld_gso_save_many); a single
+                // swarm goes through ld_gso_save, the 1:1 counterpart of Swarm::save (src/swarm.rs:128-167)
+                if output_directories.len() == 1 {
+                    let c = CString::new(output_directories[0].as_str()).unwrap();
+                    if unsafe { ld_gso_save(self.handle, 0, done, c.as_ptr()) } != 0 {
+                        panic!("Error saving GSO output: {:?}", last_error());
+                    }
+                } else {
+                    let owned: Vec<CString> = output_directories.iter().map(|d| CString::new(d.as_str()).unwrap()).collect();
+                    let ptrs: Vec<*const c_char> = owned.iter().map(|c| c.as_ptr()).collect();
+                    let ids: Vec<usize> = (0..owned.len()).collect();
+                    if unsafe { ld_gso_save_many(self.handle, ids.len(), ids.as_ptr(), ptrs.as_ptr(), done) } != 0 {
                         panic!("Error saving GSO output: {:?}", last_error());
                     }
                 }

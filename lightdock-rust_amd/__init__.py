@@ -120,6 +120,7 @@ def load_library():
     lib.ld_gso_num_evals.argtypes = [vp]
     lib.ld_gso_read.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp]
     lib.ld_gso_save.argtypes = [vp, sz, C.c_uint32, C.c_char_p]
+    lib.ld_gso_save_many.argtypes = [vp, sz, vp, vp, C.c_uint32]
     lib.ld_cli_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
     lib.ld_model_from_pdb.restype = vp
     lib.ld_model_from_pdb.argtypes = [C.c_int, C.c_char_p, vp, sz, vp, sz, vp, sz, sz]
@@ -471,7 +472,6 @@ class GSO:
         n = len(swarms)
         ids = (C.c_size_t * n)(*[int(s) for s in swarms])
         dirs = (C.c_char_p * n)(*[os.fsencode(d) for d in directories])
-        self.lib.ld_gso_save_many.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32]
         _check(self.lib.ld_gso_save_many(self._h, n, ids, dirs, step))
 
 

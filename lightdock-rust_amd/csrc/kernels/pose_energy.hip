@@ -234,10 +234,12 @@ __global__ __launch_bounds__(kBlockThreads) void pose_energy_pairs(const PairLau
             }
         } else {
             const double lq = P.lig.charge[la], le = P.lig.well_depth[la], lr = P.lig.radius[la];
+            double closest = 1.0;  // smallest d2 seen: coincident atoms make the reference's score NaN, see below
             for (int j = j_begin; j < j_end; j++) {
                 const DnaRec a = rec[j];
                 const double dx = a.x - lx, dy = a.y - ly, dz = a.z - lz;
                 const double d2 = dx * dx + dy * dy + dz * dz;  // src/dna.rs:476-478
+                closest = fmin(closest, d2);
                 if (d2 <= kElecCutoff2) {                         // src/dna.rs:481-491
                     // 1/d2 by v_rcp_f64 + two Newton steps (~1 ulp) instead of two correctly rounded
                     // f64 divisions: the energy is continuous in these terms (all cutoff tests
@@ -267,6 +269,11 @@ __global__ __launch_bounds__(kBlockThreads) void pose_energy_pairs(const PairLau
                     }
                 }
             }
+            // Two atoms on the same spot (d2 = 0, or so small that R^6 / d2^3 overflows): the reference
+            // gets p6 = inf and k = e * (inf - inf) = NaN, which its ordered `k > VDW_CUTOFF` keeps
+            // (src/dna.rs:498-503), so the score is NaN.  fmin/fmax above would turn that NaN into a
+            // clamp value; restore it.
+            if (closest < 1.0e-90) acc1 = __builtin_nan("");
         }
         if (lflag && lslot >= 0) atomicOr(&pose_flags[P.rec.flag_words + (lslot >> 5)], 1u << (lslot & 31));
     }

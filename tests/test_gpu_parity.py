@@ -361,6 +361,20 @@ def test_gso_run_graph_replay_equals_stepping(pkg, scorers, orc):
     assert a.num_evals == b.num_evals == ref.num_evals
 
 
+def test_dna_coincident_atoms_score_nan_like_the_reference(pkg, orc, tmp_path):
+    """Two atoms on the same spot: src/dna.rs:498-503 computes p6 = R^6 / 0 = inf, k = e * (inf - inf) = NaN,
+    and its ordered compare `k > VDW_CUTOFF` keeps the NaN, so the score is NaN (the oracle agrees).  The
+    kernel clamps with fmin/fmax, which drop NaNs, and must put it back."""
+    rec, lig = str(tmp_path / "r.pdb"), str(tmp_path / "l.pdb")
+    _write_pdb(rec, [("N", "ALA", "A", 1, 0.0, 0.0, 0.0), ("CA", "ALA", "A", 1, 1.4, 0.3, 0.0)])
+    _write_pdb(lig, [("N", "GLY", "B", 1, 0.0, 0.0, 0.0), ("CA", "GLY", "B", 1, 3.0, 0.0, 0.0)])
+    hip, cpu = pkg.Scorer.from_pdb("dna", rec, lig), orc.Scorer("dna", rec, lig)
+    poses = np.array([[0, 0, 0, 1, 0, 0, 0], [0.5, 0, 0, 1, 0, 0, 0]], dtype=np.float64)
+    want, got = cpu.energy_rows(poses), hip.energy_batch(poses)
+    assert np.isnan(want[0]) and np.isnan(got[0])
+    assert np.isfinite(want[1]) and abs(got[1] - want[1]) <= 1e-9 * abs(want[1])
+
+
 def test_gso_graph_survives_workspace_reallocation(pkg, scorers, orc):
     """The captured hipGraph carries the addresses of the scorer's shared workspaces.  A larger batch
     on the same scorer reallocates them between two ld_gso_run calls: the next run must capture
@@ -733,6 +747,28 @@ def test_launcher_on_the_reference_multi_swarm_example_1czy(pkg, orc, tmp_path):
                 assert np.allclose(x, y, rtol=0, atol=2e-7), name      # print precision (7 / 8 decimals)
     for s in range(10):
         assert sorted(os.listdir(run / ("swarm_%d" % s))) == ["gso_1.out", "gso_10.out", "gso_20.out"]
+
+
+def test_gso_save_many_equals_save_and_reports_errors(pkg, scorers, orc, tmp_path):
+    """ld_gso_save_many (one device read, files written by threads) writes what ld_gso_save writes swarm by
+    swarm; n = 0 is a no-op; a swarm index out of range and an unwritable directory are errors."""
+    hip, _ = scorers("1ppe")
+    poses = case_positions("1ppe", orc)
+    gso = pkg.GSO(hip, np.stack([poses[:64], poses[64:128], poses[128:192]]))
+    gso.run(10)
+    one, many = tmp_path / "one", tmp_path / "many"
+    for s in range(3):
+        (one / str(s)).mkdir(parents=True)
+        (many / str(s)).mkdir(parents=True)
+        gso.save(s, 10, str(one / str(s)))
+    gso.save_many([2, 0, 1], 10, [str(many / "2"), str(many / "0"), str(many / "1")])
+    for s in range(3):
+        assert open(one / str(s) / "gso_10.out").read() == open(many / str(s) / "gso_10.out").read()
+    gso.save_many([], 10, [])
+    with pytest.raises(pkg.LightdockError):
+        gso.save_many([3], 10, [str(many / "0")])
+    with pytest.raises(pkg.LightdockError):
+        gso.save_many([0], 10, [str(tmp_path / "missing" / "dir")])
 
 
 def test_block_count_diagnostics(pkg, scorers, orc):
