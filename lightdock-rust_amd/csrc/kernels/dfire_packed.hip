@@ -324,8 +324,10 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_MIN_BLOCKS) void dfire
             item_id ^= item_id >> half;
         } while (item_id >= total_items);
     }
-    const size_t pose = (size_t)(item_id / (unsigned)T.n_groups);
+    const size_t listed = (size_t)(item_id / (unsigned)T.n_groups);
     const int group = (int)(item_id % (unsigned)T.n_groups);
+    if (T.pose_count != nullptr && listed >= (size_t)*T.pose_count) return;  // beyond the list of this step
+    const size_t pose = T.pose_list ? (size_t)T.pose_list[listed] : listed;
     if (T.active != nullptr && T.active[pose] == 0) return;
 
     for (int i = tid; i < kPackedLutCells * SC / 4; i += kPackedWaves * 64)

@@ -98,7 +98,12 @@ struct PackedLaunch {
     const double *poses = nullptr;
     size_t stride = 0;
     const uint8_t *active = nullptr;
-    size_t n_poses = 0;
+    size_t n_poses = 0;                  // rows in `poses`; upper bound of *pose_count
+    // GSO: the rows to evaluate as a list compacted by K2 (src/glowworm.rs:62: only the glowworms that
+    // moved).  The count lives on the device only: the launch covers n_poses rows and the workgroups
+    // beyond the count leave on one scalar load.  Both null for a plain batch.
+    const uint32_t *pose_list = nullptr;
+    const uint32_t *pose_count = nullptr;
     double *partial = nullptr;           // [pose][group][2]
     uint32_t *flags = nullptr;
     uint32_t *count_partial = nullptr;   // [pose][group] or nullptr

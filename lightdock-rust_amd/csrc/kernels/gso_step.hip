@@ -217,7 +217,10 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
         G.n_neighbors[base + i] = cnt;
         G.target[base + i] = chosen;
         G.step[base + i] = done + 1;  // glowworm.rs:71
-        if (moved) atomicAdd(G.evals, 1ULL);  // integer: order independent
+        if (moved) {
+            atomicAdd(G.evals, 1ULL);  // integer: order independent
+            if (G.moved_list) G.moved_list[atomicAdd(G.moved_count, 1u)] = (uint32_t)(base + i);
+        }
     }
 }
 

@@ -32,6 +32,10 @@ struct GsoLaunch {
     int parts = 1;                    // workgroups per swarm; each moves a contiguous share of the glowworms
     const uint32_t *rng_key = nullptr;  // per swarm: 8 ChaCha key words (rand 0.7.3 StdRng)
     unsigned long long *evals = nullptr;  // running count of energy evaluations (adds #moved)
+    // out: the glowworms that moved, compacted (any order): the next step's K1 evaluates exactly these
+    // (src/glowworm.rs:62).  *moved_count must be zero at launch.
+    uint32_t *moved_list = nullptr;
+    uint32_t *moved_count = nullptr;
 };
 
 size_t gso_kernel_lds_bytes(const GsoLaunch &g);

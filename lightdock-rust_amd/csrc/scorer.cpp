@@ -674,7 +674,7 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
 }
 
 void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride, const uint8_t *d_active,
-                                 double *d_energies, uint32_t *d_pair_counts) {
+                                 double *d_energies, uint32_t *d_pair_counts, const uint32_t *d_list, const uint32_t *d_count) {
     if (n == 0) return;
     if (!d_poses || !d_energies) throw Error(LD_ERR_INVALID, "energy_batch: null pose/energy buffer");
     if (stride < pose_len()) throw Error(LD_ERR_INVALID, "energy_batch: stride shorter than a pose row");
@@ -694,7 +694,7 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
             for (size_t off = 0; off < n; off += max_n)
                 energy_batch_device(std::min(max_n, n - off), d_poses + off * stride, stride,
                                     d_active ? d_active + off : nullptr, d_energies + off,
-                                    d_pair_counts ? d_pair_counts + off : nullptr);
+                                    d_pair_counts ? d_pair_counts + off : nullptr);  // slices go by the mask, not the list
             return;
         }
     }
@@ -733,7 +733,9 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
         PackedLaunch t = packed_;
         t.poses = d_poses;
         t.stride = stride;
-        t.active = d_active;
+        t.active = d_list ? nullptr : d_active;  // the list holds exactly the active rows
+        t.pose_list = d_list;
+        t.pose_count = d_list ? d_count : nullptr;
         t.n_poses = n;
         t.partial = p.partial;
         t.flags = p.flags;

@@ -89,9 +89,12 @@ class Scorer {
     // hipGraph captured before that replays kernels into freed memory and must be captured again.
     uint64_t workspace_generation() const;
 
-    // Enqueue K1 for n poses already in HBM.  active / pair_counts may be null.
+    // Enqueue K1 for n poses already in HBM.  active / pair_counts may be null.  d_list / d_count
+    // (device): the rows to evaluate as a compacted list whose length only the device knows (the GSO
+    // loop: the glowworms that moved); they must be the rows `d_active` marks.
     void energy_batch_device(size_t n, const double *d_poses, size_t stride, const uint8_t *d_active,
-                             double *d_energies, uint32_t *d_pair_counts);
+                             double *d_energies, uint32_t *d_pair_counts, const uint32_t *d_list = nullptr,
+                             const uint32_t *d_count = nullptr);
     // Host-pointer convenience: H2D, kernels, D2H, synchronise.
     void energy_batch_host(size_t n, const double *poses, size_t stride, double *energies);
 
