@@ -302,14 +302,19 @@ def test_real_dcparams_goldens_on_gpu(pkg, orc, real_dcparams):
 
 @pytest.mark.parametrize("env", [
     {"LIGHTDOCK_DFIRE_KERNEL": "allpairs"},
-    {"LIGHTDOCK_TILED_WAVES": "3"},
-    {"LIGHTDOCK_TILED_WAVES": "16"},
+    {"LIGHTDOCK_DFIRE_KERNEL": "tiled"},
+    {"LIGHTDOCK_DFIRE_KERNEL": "tiled", "LIGHTDOCK_TILED_WAVES": "3"},
+    {"LIGHTDOCK_DFIRE_KERNEL": "tiled", "LIGHTDOCK_TILED_WAVES": "16"},
+    {"LIGHTDOCK_PACKED_CELLS": "1"},
+    {"LIGHTDOCK_PACKED_EPS_SCALE": "8"},      # a wider error band: more pairs on the exact path, same results
+    {"LIGHTDOCK_TILED_SPLIT": "2"},
 ])
 @pytest.mark.parametrize("name", ["1ppe", "1k4c", "2uuy"])
 def test_dfire_kernel_variants_agree(pkg, orc, table, scorers, name, env):
-    """The all-pairs kernel and the box-culled tiled kernel (in several workgroup shapes) are
-    two routes to the same sum: both match the oracle,
-    and the in-cutoff pair counts -- which no culling may change -- are identical."""
+    """The all-pairs kernel, the box-culled f64 kernel (in several workgroup shapes) and the default
+    kernel (box culling + packed-f32 pair test with exact f64 path, in several settings) are routes to the
+    same sum: all match the oracle, and the in-cutoff pair counts -- which neither culling nor the f32
+    test may change by a single pair -- are identical."""
     torch = pytest.importorskip("torch")
     default_hip, cpu = scorers(name)
     method, rec, lig, kw = case_kwargs(name, orc, table)
@@ -373,6 +378,34 @@ def test_dna_coincident_atoms_score_nan_like_the_reference(pkg, orc, tmp_path):
     want, got = cpu.energy_rows(poses), hip.energy_batch(poses)
     assert np.isnan(want[0]) and np.isnan(got[0])
     assert np.isfinite(want[1]) and abs(got[1] - want[1]) <= 1e-9 * abs(want[1])
+
+
+def test_atoms_outside_the_f32_frame_take_the_exact_path(pkg, orc, table):
+    """The default DFIRE kernel keeps f32 records in a frame around the receptor; atoms outside it (absurd
+    ANM extents here: coefficients of hundreds of angstroms) are flagged and every pair of theirs is
+    decided in f64 -- through the per-wave queue or, when that overflows, the all-f64 pass of the wave.
+    Energies and in-cutoff pair counts must still equal the oracle's."""
+    torch = pytest.importorskip("torch")
+    method, rec, lig, kw = case_kwargs("2uuy", orc, table)
+    hip, cpu = pkg.Scorer.from_pdb(method, rec, lig, **kw), orc.Scorer(method, rec, lig, **kw)
+    poses = case_positions("2uuy", orc)[:24].copy()
+    rng = np.random.default_rng(9)
+    poses[:8, 7:17] *= 400.0                                  # receptor modes: atoms fly out of the frame
+    poses[8:16, 17:27] *= 400.0                               # ligand modes
+    poses[16:20, :3] += rng.normal(0.0, 300.0, size=(4, 3))   # ligand far away: nothing in range
+    want = np.array([cpu.energy_ex_row(p) for p in poses], dtype=object)
+    want_e = np.array([w[0] for w in want], dtype=np.float64)
+    want_n = np.array([w[1][5] for w in want]).astype(np.int64)
+    dev = torch.device("cuda:0")
+    d_poses = torch.from_numpy(poses).to(dev)
+    d_out = torch.zeros(len(poses), dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(len(poses), dtype=torch.int32, device=dev)
+    hip.energy_batch_device(len(poses), d_poses.data_ptr(), poses.shape[1], d_out.data_ptr(), None, d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_cnt.cpu().numpy().astype(np.int64), want_n)
+    assert rel_err(d_out.cpu().numpy(), want_e) < REL_TOL
+    assert rel_err(hip.energy_batch(poses), want_e) < REL_TOL
+    assert want_n[:16].max() > 0 and np.all(want_n[16:20] == 0)
 
 
 def test_gso_graph_survives_workspace_reallocation(pkg, scorers, orc):
