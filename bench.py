@@ -84,6 +84,27 @@ def cpu_model():
     return "unknown"
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, cut by a cgroup CPU quota if there is one
+    (a container with 64 visible CPUs and a quota of 16 scales to 16, whatever the thread count)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            text = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if text[0] != "max":
+                    quota = float(text[0]) / float(text[1])
+            else:
+                q = float(text[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n, quota
+
+
 def cpu_baseline(case, table, poses, budget_s, threads):
     """Time the CPU oracle (test infrastructure used ONLY as the reported baseline) over a bounded
     sample of the bench poses: (a) one thread, the stand-in for the single-threaded Rust path;
@@ -309,8 +330,11 @@ def main():
                          "evaluated_pair_tests_per_s": (64.0 * blocks * units_per_launch / kern_s) if blocks else None},
         }
         if args.cpu_seconds > 0 and world == 1:      # reported baseline: rank 0 at N = 1 only
-            threads = min(len(os.sched_getaffinity(0)), 64)
+            visible, quota = host_cores()
+            threads = min(visible, 64)
             cb, cpu_e = cpu_baseline(case, table, cpu_poses, args.cpu_seconds, threads)
+            cb["visible_cpus"] = visible
+            cb["cgroup_cpu_quota"] = quota       # None = unlimited; the 64-thread figure cannot exceed quota x single thread
             out["cpu_baseline"] = cb
             n = min(len(cpu_e), len(energies))
             rel = float(np.max(np.abs(energies[:n] - cpu_e[:n]) / np.maximum(np.abs(cpu_e[:n]), 1e-9)))
