@@ -17,7 +17,7 @@ namespace ld {
 constexpr int kTiledMaxWaves = 16;
 // The tiled kernel reads the potential in 128-byte patches of 2 ligand types x 2 receptor types
 // x 4 distance bins:
-//   index = ((l/2)*84 + r/2)*96 + (bin/4)*16 + (l%2)*8 + (r%2)*4 + bin%4        (bin 0..20)
+//   index = ((l/2)*85 + r/2)*96 + (bin/4)*16 + (l%2)*8 + (r%2)*4 + bin%4        (bin 0..20; 169 types -> 85 pairs)
 // The atoms of a subtile are mostly one residue, whose DFIRE types are consecutive numbers, and
 // bonded atoms sit in the same or the next distance bin of a given partner, so the hits of one
 // 8x8 block fall into fewer distinct cache lines than with any row-major order (simulated on the
