@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r2_pytest.log 2>&1; echo "pytest rc=$?"; tail -15 gpurun_out/r2_pytest.log | cut -c1-250
+timeout 300 python tools/debug_packed.py 1ppe 1k4c 2uuy 2>&1 | grep -v "tiled\|allpairs\|amdgpu.ids"
+for i in 1 2; do timeout 100 python bench.py --cpu-seconds 0 --steps 10 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.0f evals/s kernel %.3f ms blocks %s' % (d['value'], d['roofline']['kernel_ms'], d['config']['mean_8x8_blocks_evaluated']))"; done
+timeout 100 python bench.py --workload 1ppe --cpu-seconds 0 2>&1 | tail -1 | cut -c1-120
