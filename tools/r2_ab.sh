@@ -1,4 +1,9 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python tools/debug_packed.py 1ppe 1k4c 2uuy 2>&1 | grep -v "tiled\|allpairs\|amdgpu.ids"
-for i in 1 2; do timeout 100 python bench.py --cpu-seconds 0 --steps 10 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.0f evals/s kernel %.3f ms blocks %s' % (d['value'], d['roofline']['kernel_ms'], d['config']['mean_8x8_blocks_evaluated']))"; done
-timeout 100 python bench.py --workload 1ppe --cpu-seconds 0 2>&1 | tail -1 | cut -c1-120
+L=lightdock-rust_amd/lib
+cp $L/liblightdock_hip.so /tmp/keep.so
+for v in base dna1; do
+  cp $L/variants/$v.so $L/liblightdock_hip.so
+  echo "== $v"; timeout 200 python bench.py --workload 1azp-dna --cpu-seconds 20 --steps 10 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.0f evals/s kernel %.3f ms parity %.3e' % (d['value'], d['roofline']['kernel_ms'], d['parity_max_rel_err_vs_cpu_sample']))"
+  timeout 300 python -m pytest tests -m gpu -x -q -k "dna or 1azp or pydock" 2>&1 | tail -2
+done
+cp /tmp/keep.so $L/liblightdock_hip.so
