@@ -405,13 +405,13 @@ void Scorer::build_tiled(const ld_scorer_desc &desc) {
     // `split` items share one ligand tile, each taking every split-th surviving receptor tile.
     // With thousands of poses per launch there are enough waves anyway and split = 1 is best or
     // equal (measured on MI355X at 16 384+ poses: 2uuy, 7 ligand tiles, +12 % over split 3; 1k4c,
-    // 52 tiles, +11 %; 1ppe, 4 tiles, equal).  A launch of one swarm (200 poses) of a small ligand
+    // 52 tiles, +11 %; 1ppe, 4 tiles, +5 % with the packed kernel).  A launch of one swarm (200 poses) of a small ligand
     // does not fill the GPU: split 3 halves its latency on 1ppe.  The split is fixed per scorer (a
     // pose's energy must not depend on the batch it travels in), so the default serves
     // throughput and LIGHTDOCK_TILED_LATENCY=1 -- set by the single-swarm CLI -- serves latency.
     // Splits sharing a factor with the 4 waves of a workgroup (2, 4) are consistently slower.
     const char *latency = std::getenv("LIGHTDOCK_TILED_LATENCY");
-    const int small_ligand = (latency && std::atoi(latency) > 0) ? 32 : 5;
+    const int small_ligand = (latency && std::atoi(latency) > 0) ? 32 : 0;
     int split = tiled_.lig.n_tiles < small_ligand ? 3 : 1;
     if (const char *e = std::getenv("LIGHTDOCK_TILED_SPLIT")) {
         int v = std::atoi(e);
