@@ -313,6 +313,11 @@ def main():
             compute = {"bound": "vector issue (f64/f32 VALU, one op per lane per cycle)", "achieved": lane_ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
                        "unit": "T lane-ops/s", "frac": lane_ops / VALU_LANE_OPS_PER_S,
                        "valu_insts_per_launch": prof["valu_insts_per_launch"], "source": prof.get("valu_source")}
+        l1 = None
+        if prof.get("tcp_cache_accesses_per_launch"):     # one tag lookup per cycle per CU
+            rate = prof["tcp_cache_accesses_per_launch"] / kern_s
+            l1 = {"bound": "L1 (TCP) tag lookups, one per cycle per CU", "achieved": rate / 1e9, "peak": 256 * 2.4, "unit": "G lookups/s",
+                  "frac": rate / (256 * 2.4e9), "l2_read_requests_per_launch": prof.get("l2_read_requests_per_launch")}
         out = {
             "metric": "pose-energy evals/sec (%s, %s)" % (case["method"].upper(), args.workload),
             "value": total_evals / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -325,7 +330,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "note": "algorithmic bytes (SURVEY 8d) over kernel time; the working set is L2 resident, so measured HBM "
                                  "traffic (`traffic`) is far below it and the binding limits are on chip -- see `compute`",
-                         "compute": compute,
+                         "compute": compute, "l1": l1,
                          "nominal_pair_tests_per_s": info["pair_tests_per_pose"] * units_per_launch / kern_s,
                          "evaluated_pair_tests_per_s": (64.0 * blocks * units_per_launch / kern_s) if blocks else None},
         }
