@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for sp in 1 2 3 4; do
-  for w in 1ppe gso-1ppe; do
-  echo "== split $sp $w: $(LIGHTDOCK_TILED_SPLIT=$sp timeout 200 python bench.py --workload $w --cpu-seconds 0 --steps 10 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.0f evals/s kernel %.3f ms' % (d['value'], d['roofline']['kernel_ms']))")"
-  done
-done
-for c in 1 2; do echo "== cells $c 1k4c: $(LIGHTDOCK_PACKED_CELLS=$c timeout 200 python bench.py --cpu-seconds 0 --steps 10 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.0f evals/s kernel %.3f ms' % (d['value'], d['roofline']['kernel_ms']))")"; done
+timeout 300 python tools/debug_packed.py 1ppe 1k4c 2uuy 2>&1 | grep -v "tiled\|allpairs\|amdgpu.ids\|eps50"
+for i in 1 2; do timeout 100 python bench.py --cpu-seconds 0 --steps 10 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.0f evals/s kernel %.3f ms' % (d['value'], d['roofline']['kernel_ms']))"; done
+timeout 100 python bench.py --workload 1ppe --cpu-seconds 0 2>&1 | tail -1 | cut -c1-120
+timeout 200 python bench.py --workload gso-1ppe --cpu-seconds 0 --steps 10 2>&1 | tail -1 | cut -c1-120
