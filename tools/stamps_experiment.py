@@ -23,6 +23,8 @@ try:
     waves = d[5]
     print("waves %d  cycles/wave total %.0f  setup %.0f (%.1f%%)  dma+subbox %.0f (%.1f%%)  block loop %.0f (%.1f%%)  other %.0f (%.1f%%); tiles/wave %.1f; per tile: dma %.0f loop %.0f" % (
         waves, d[0]/waves, d[1]/waves, 100*d[1]/d[0], d[2]/waves, 100*d[2]/d[0], d[3]/waves, 100*d[3]/d[0], (d[0]-d[1]-d[2]-d[3])/waves, 100*(d[0]-d[1]-d[2]-d[3])/d[0], d[4]/waves, d[2]/d[4], d[3]/d[4]))
+    if d[7] > 0:
+        print("balance inside a workgroup: sum of wave cycles / (slowest wave x waves) = %.3f" % (d[0] / d[7]))
     if d[6] > 0:
         print("trips/wave %.1f  trips/pose %.0f  loop cycles per trip %.0f" % (d[6]/waves, d[6]/8192, d[3]/d[6]))
 finally:
