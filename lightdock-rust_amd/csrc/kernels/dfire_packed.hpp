@@ -32,10 +32,15 @@
 
 namespace ld {
 
+// Wave64s per workgroup, one ligand tile each.  One: the tiles of a pose differ widely in work (four waves
+// behind one barrier are busy 64 % of the time the slowest takes) and a wave that is done frees its slot at
+// once; the price is a cell LUT per wave, which is why the default LUT has one cell per unit then
+// (6.6 KiB of LDS per wave, 6 waves per SIMD).  Measured against 4 (MI355X, same box): 1k4c +2.3..4.5 %,
+// GSO 1k4c +4.5 %, GSO 1ppe +1.7 %, 1ppe equal.
 #ifndef LD_PACKED_WAVES
-#define LD_PACKED_WAVES 4
+#define LD_PACKED_WAVES 1
 #endif
-constexpr int kPackedWaves = LD_PACKED_WAVES;  // wave64s per workgroup, one ligand tile each
+constexpr int kPackedWaves = LD_PACKED_WAVES;
 constexpr int kPackedLutCells = 1028;    // per cell of 4 d2: cells 0..1024 (1024 = everything further), padded to 16 bytes
 constexpr float kPackedCellMax = 1024.0f;
 constexpr int kPackedQueue = 64;         // per wave: pairs waiting for the exact f64 path

@@ -323,19 +323,31 @@ __device__ double satisfied_fraction(const uint32_t *words, int n_groups, const 
     return (double)hit / (double)n_groups;
 }
 
-// One thread per pose: fold the chunk partials in chunk order and apply the tail.
+// Eight lanes per pose: lane k folds the partials k, k + 8, ... in that order, the eight sums are folded as a
+// fixed tree (the same for every launch), lane 0 applies the tail.
+constexpr int kFinishLanes = 8;
 __global__ __launch_bounds__(kBlockThreads) void pose_energy_finish(const FinishLaunch F) {
-    const size_t pose = (size_t)blockIdx.x * kBlockThreads + threadIdx.x;
-    if (pose >= F.n_poses) return;
-    if (F.active != nullptr && F.active[pose] == 0) return;
+    const size_t t = (size_t)blockIdx.x * kBlockThreads + threadIdx.x;
+    const size_t pose = t / kFinishLanes;
+    const int sub = (int)(t % kFinishLanes);
+    const bool live = pose < F.n_poses && !(F.active != nullptr && F.active[pose] == 0);
     double s0 = 0.0, s1 = 0.0;
     uint32_t cnt = 0;
-    for (int c = 0; c < F.n_chunks; c++) {
-        const size_t slot = pose * (size_t)F.n_chunks + c;
-        s0 += F.partial[2 * slot];
-        s1 += F.partial[2 * slot + 1];
-        if (F.count_partial) cnt += F.count_partial[slot];
+    if (live) {
+        for (int c = sub; c < F.n_chunks; c += kFinishLanes) {
+            const size_t slot = pose * (size_t)F.n_chunks + c;
+            const double2 v = *reinterpret_cast<const double2 *>(F.partial + 2 * slot);
+            s0 += v.x;
+            s1 += v.y;
+            if (F.count_partial) cnt += F.count_partial[slot];
+        }
     }
+    for (int d = 1; d < kFinishLanes; d <<= 1) {  // every lane of the wave takes part: dead poses carry zeros
+        s0 += __shfl_xor(s0, d);
+        s1 += __shfl_xor(s1, d);
+        cnt += __shfl_xor(cnt, d);
+    }
+    if (!live || sub != 0) return;
     double score;
     if (F.method == 0) {
         score = (s0 * 0.0157 - 4.7) * -1.0;  // src/dfire.rs:347
@@ -387,7 +399,7 @@ hipError_t launch_pair_kernel(const PairLaunch &p, hipStream_t stream) {
 
 hipError_t launch_finish_kernel(const FinishLaunch &f, hipStream_t stream) {
     if (f.n_poses == 0) return hipSuccess;
-    const dim3 grid((unsigned)((f.n_poses + kBlockThreads - 1) / kBlockThreads)), block(kBlockThreads);
+    const dim3 grid((unsigned)((f.n_poses * kFinishLanes + kBlockThreads - 1) / kBlockThreads)), block(kBlockThreads);
     hipLaunchKernelGGL(pose_energy_finish, grid, block, 0, stream, f);
     return hipGetLastError();
 }

@@ -530,7 +530,7 @@ void Scorer::build_packed(const ld_scorer_desc &desc) {
         half = std::max(half, 0.5 * (hi[c] - lo[c]));
     }
     // LUT cells per unit of 4 d2: 2 halves the share of pairs in flagged cells for 4 KiB more LDS
-    int sc = 2;
+    int sc = kPackedWaves == 1 ? 1 : 2;  // one-wave workgroups: the LUT is per wave, the smaller one keeps 6 waves per SIMD
     if (const char *e = std::getenv("LIGHTDOCK_PACKED_CELLS")) sc = std::atoi(e) == 1 ? 1 : 2;
     const double kappa = 2.0 * std::sqrt((double)sc);
     // records hold kappa (x - c); room for the cutoff and for ANM deformations (32 A), rounded up to a power of two

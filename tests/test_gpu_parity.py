@@ -345,8 +345,9 @@ def test_dfire_kernel_variants_agree(pkg, orc, table, scorers, name, env):
     assert np.array_equal(counts[0][:16].astype(np.int64), stats.astype(np.int64))
 
 
-def test_gso_run_graph_replay_equals_stepping(pkg, scorers, orc):
-    """ld_gso_run (captured hipGraph, two steps per replay) == ld_gso_step repeated == oracle."""
+def test_gso_run_graph_replay_equals_stepping(pkg, scorers, orc, monkeypatch):
+    """ld_gso_run with LIGHTDOCK_GSO_GRAPH=1 (captured hipGraph, two steps per replay) == ld_gso_step repeated == oracle."""
+    monkeypatch.setenv("LIGHTDOCK_GSO_GRAPH", "1")
     hip, cpu = scorers("1ppe")
     poses = case_positions("1ppe", orc)
     a, b = pkg.GSO(hip, poses), pkg.GSO(hip, poses)
@@ -408,10 +409,11 @@ def test_atoms_outside_the_f32_frame_take_the_exact_path(pkg, orc, table):
     assert want_n[:16].max() > 0 and np.all(want_n[16:20] == 0)
 
 
-def test_gso_graph_survives_workspace_reallocation(pkg, scorers, orc):
+def test_gso_graph_survives_workspace_reallocation(pkg, scorers, orc, monkeypatch):
     """The captured hipGraph carries the addresses of the scorer's shared workspaces.  A larger batch
     on the same scorer reallocates them between two ld_gso_run calls: the next run must capture
     again instead of replaying launches into freed memory."""
+    monkeypatch.setenv("LIGHTDOCK_GSO_GRAPH", "1")
     hip, cpu = scorers("1ppe")
     poses = case_positions("1ppe", orc)
     a, b = pkg.GSO(hip, poses), pkg.GSO(hip, poses)

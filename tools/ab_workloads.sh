@@ -1,0 +1,14 @@
+# A/B of the library variants under lightdock-rust_amd/lib/variants over several bench workloads (GPU box)
+cd $GRAFT_REPO_ROOT
+L=lightdock-rust_amd/lib
+cp $L/liblightdock_hip.so /tmp/keep.so
+for w in "$@"; do
+  for round in 1 2; do
+    for v in $L/variants/*.so; do
+      cp $v $L/liblightdock_hip.so
+      r=$(timeout 200 python bench.py --cpu-seconds 0 --workload $w --steps 10 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.0f evals/s kernel %.3f ms' % (d['value'], d['roofline']['kernel_ms']))" 2>&1 | tail -1)
+      echo "$w $(basename $v) $r"
+    done
+  done
+done
+cp /tmp/keep.so $L/liblightdock_hip.so
