@@ -44,6 +44,8 @@ import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                      # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one vector op per lane per cycle
+L2_PEAK_GBS = 34500.0                      # aggregate L2 bandwidth, same guide ("L2 (per XCD)": ~34.5 TB/s)
+L2_REQUEST_BYTES = 128                     # one TCP_TCC_READ_REQ = one 128-byte line (tools/microbench/l2_request_size.py)
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
@@ -316,6 +318,12 @@ def main():
             rate = prof["tcp_cache_accesses_per_launch"] / kern_s
             l1 = {"bound": "L1 (TCP) tag lookups, one per cycle per CU", "achieved": rate / 1e9, "peak": 256 * 2.4, "unit": "G lookups/s",
                   "frac": rate / (256 * 2.4e9), "l2_read_requests_per_launch": prof.get("l2_read_requests_per_launch")}
+        l2 = None
+        if prof.get("l2_read_requests_per_launch"):      # what binds the DFIRE gather: lines filled into the L1s
+            rate = L2_REQUEST_BYTES * prof["l2_read_requests_per_launch"] / kern_s / 1e9
+            l2 = {"bound": "L2 -> L1 fills (128-byte lines)", "achieved": rate, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": rate / L2_PEAK_GBS,
+                  "l2_read_requests_per_launch": prof["l2_read_requests_per_launch"],
+                  "source": "TCP_TCC_READ_REQ_sum per launch of the pair kernel (profiles/), 128 bytes each"}
         out = {
             "metric": "pose-energy evals/sec (%s, %s)" % (case["method"].upper(), args.workload),
             "value": total_evals / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -327,8 +335,8 @@ def main():
                          "kernel": info["pair_kernel_name"], "kernel_ms": 1e3 * kern_s,
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "note": "algorithmic bytes (SURVEY 8d) over kernel time; the working set is L2 resident, so measured HBM "
-                                 "traffic (`traffic`) is far below it and the binding limits are on chip -- see `compute`",
-                         "compute": compute, "l1": l1,
+                                 "traffic (`traffic`) is far below it and the binding limits are on chip -- see `l2`, `l1`, `compute`",
+                         "compute": compute, "l1": l1, "l2": l2,
                          "nominal_pair_tests_per_s": info["pair_tests_per_pose"] * units_per_launch / kern_s,
                          "evaluated_pair_tests_per_s": (64.0 * blocks * units_per_launch / kern_s) if blocks else None},
         }

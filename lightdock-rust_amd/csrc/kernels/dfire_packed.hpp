@@ -41,6 +41,13 @@ namespace ld {
 #define LD_PACKED_WAVES 1
 #endif
 constexpr int kPackedWaves = LD_PACKED_WAVES;
+// LD_PACKED_FREE_WAVES: the waves of a workgroup share the LUT but nothing else -- no closing barrier,
+// one partial per wave
+#ifdef LD_PACKED_FREE_WAVES
+constexpr int kPackedPartialsPerGroup = kPackedWaves;
+#else
+constexpr int kPackedPartialsPerGroup = 1;
+#endif
 constexpr int kPackedLutCells = 1028;    // per cell of 4 d2: cells 0..1024 (1024 = everything further), padded to 16 bytes
 constexpr float kPackedCellMax = 1024.0f;
 constexpr int kPackedQueue = 64;         // per wave: pairs waiting for the exact f64 path

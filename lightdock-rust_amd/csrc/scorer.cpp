@@ -663,7 +663,7 @@ uint64_t Scorer::workspace_generation() const {
 
 void Scorer::reserve_workspace(size_t n_poses, bool counts) {
     const size_t words = (size_t)(pair_.rec.flag_words + pair_.lig.flag_words);
-    const size_t chunks = (size_t)std::max(pair_.n_chunks, use_packed_ ? packed_.n_groups : use_tiled_ ? tiled_.n_groups : 0);
+    const size_t chunks = (size_t)std::max(pair_.n_chunks, use_packed_ ? packed_.n_groups * kPackedPartialsPerGroup : use_tiled_ ? tiled_.n_groups : 0);
     ws_partial_.reserve(n_poses * chunks * 2 * sizeof(double));
     ws_flags_.reserve(std::max<size_t>(n_poses * words * sizeof(uint32_t), 16));
     if (counts) {
@@ -742,7 +742,7 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
         t.count_partial = p.count_partial;
         t.tested_partial = p.count_partial ? static_cast<uint32_t *>(ws_tested_.ptr) : nullptr;
         t.exact_partial = p.count_partial ? static_cast<uint32_t *>(ws_exact_.ptr) : nullptr;
-        p.n_chunks = t.n_groups;  // the tail kernel folds this many partials
+        p.n_chunks = t.n_groups * kPackedPartialsPerGroup;  // the tail kernel folds this many partials
         if (rec_anm_per_pose_) {  // one deformed receptor image per pose (src/dfire.rs:304-320)
             const size_t pad = (size_t)t.rec.n_tiles * 64;
             ws_rec_pairs_.reserve(n * (pad / 2) * sizeof(PackedRecPair));
@@ -835,7 +835,7 @@ void Scorer::energy_batch_host(size_t n, const double *poses, size_t stride, dou
 void Scorer::last_block_counts(size_t n, uint32_t *out_host) {
     if (!use_tiled_) throw Error(LD_ERR_UNSUPPORTED, "block counts exist for the tiled DFIRE kernel only");
     if (!out_host) throw Error(LD_ERR_INVALID, "null output");
-    const size_t groups = (size_t)(use_packed_ ? packed_.n_groups : tiled_.n_groups);
+    const size_t groups = (size_t)(use_packed_ ? packed_.n_groups * kPackedPartialsPerGroup : tiled_.n_groups);
     if (ws_tested_.bytes < n * groups * sizeof(uint32_t)) throw Error(LD_ERR_INVALID, "no counting launch of that size has run");
     std::vector<uint32_t> part(n * groups);
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
