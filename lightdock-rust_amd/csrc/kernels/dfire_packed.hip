@@ -159,19 +159,46 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Receptor image: one wave per (pose, receptor tile); lane = atom.
+// Receptor image: one wave per (receptor tile, 16 poses); lane = atom, the tile's modes stay in registers.
 // ---------------------------------------------------------------------------------------------
+constexpr int kPreparePoses = 16;   // poses per workgroup: the tile's modes are read once for all of them
+constexpr int kPrepareModes = 10;   // modes kept in registers; any further ones are read per pose
 __global__ __launch_bounds__(64) void dfire_packed_prepare(const PackedPrepareLaunch P) {
-    const size_t pose = blockIdx.x / (unsigned)P.n_tiles;
     const int tile = blockIdx.x % (unsigned)P.n_tiles;
-    if (P.active != nullptr && P.active[pose] == 0) return;
+    const size_t pose0 = (size_t)(blockIdx.x / (unsigned)P.n_tiles) * kPreparePoses;
     const int lane = threadIdx.x;
     const int a = tile * 64 + lane;
     const size_t pad = (size_t)P.n_tiles * 64;
-    double x = P.x[a], y = P.y[a], z = P.z[a];
+    const double x0 = P.x[a], y0 = P.y[a], z0 = P.z[a];
+    double mx[kPrepareModes], my[kPrepareModes], mz[kPrepareModes];
+#pragma unroll
+    for (int k = 0; k < kPrepareModes; k++) {
+        const bool have = k < P.num_anm;
+        const double *m = P.modes + (size_t)(have ? k : 0) * 3 * pad;
+        mx[k] = have ? m[a] : 0.0;
+        my[k] = have ? m[pad + a] : 0.0;
+        mz[k] = have ? m[2 * pad + a] : 0.0;
+    }
+    const bool real = a < P.n_real;  // padding sits at x = -1e30 (scorer.cpp)
+    const uint32_t my_term = P.tindex[a];
+    const unsigned long long tracked = __ballot(real && P.slot[a] >= 0);  // atoms with an interface-flag slot
+    for (int i = 0; i < kPreparePoses; i++) {
+    const size_t pose = pose0 + i;
+    if (pose >= P.n_poses) break;
+    if (P.active != nullptr && P.active[pose] == 0) continue;
+    double x = x0, y = y0, z = z0;
     if (P.num_anm > 0) {  // src/dfire.rs:304-320
         const double *rec_nm = P.poses + pose * P.stride + 7;
-        for (int k = 0; k < P.num_anm; k++) {
+#pragma unroll
+        for (int k = 0; k < kPrepareModes; k++) {
+            if (k < P.num_anm) {
+                const double c = rec_nm[k];
+                x += mx[k] * c;
+                y += my[k] * c;
+                z += mz[k] * c;
+            }
+        }
+        for (int k = kPrepareModes; k < P.num_anm; k++) {
             const double c = rec_nm[k];
             const double *m = P.modes + (size_t)k * 3 * pad;
             x += m[a] * c;
@@ -179,13 +206,6 @@ __global__ __launch_bounds__(64) void dfire_packed_prepare(const PackedPrepareLa
             z += m[2 * pad + a] * c;
         }
     }
-    if (P.xyz_out != nullptr) {
-        double *o = P.xyz_out + pose * 3 * pad;
-        o[a] = x;
-        o[pad + a] = y;
-        o[2 * pad + a] = z;
-    }
-    const bool real = a < P.n_real;  // padding sits at x = -1e30 (scorer.cpp)
     const float fx = frame_coord(x, P.cx, P.kappa), fy = frame_coord(y, P.cy, P.kappa), fz = frame_coord(z, P.cz, P.kappa);
     const bool inside = fabsf(fx) <= P.ubound && fabsf(fy) <= P.ubound && fabsf(fz) <= P.ubound;
     // record (4 j + q) of the tile holds the atoms (2 q, 2 q + 1) of its subtile j
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(64) void dfire_packed_prepare(const PackedPrepareLa
     rec[h] = real ? fx : -1.0e30f;
     rec[2 + h] = real ? fy : 0.f;
     rec[4 + h] = real ? fz : 0.f;
-    reinterpret_cast<uint32_t *>(rec)[6 + h] = P.tindex[a] | (real && !inside ? kPackedSlow : 0u);
+    reinterpret_cast<uint32_t *>(rec)[6 + h] = my_term | (real && !inside ? kPackedSlow : 0u);
     BoxRegs b = lane_box(real, fx, fy, fz);
     box_reduce8(b);
     {
@@ -205,12 +225,12 @@ __global__ __launch_bounds__(64) void dfire_packed_prepare(const PackedPrepareLa
     box_reduce64_from8(b);
     box_widen(b);
     // atoms with an interface-flag slot (restraint atoms, membrane beads): one bit per atom of the tile
-    const unsigned long long tracked = __ballot(real && P.slot[a] >= 0);
     if (lane == 63) {
         TiledBox t = to_box(b);
         t.pad0 = __uint_as_float((uint32_t)tracked);
         t.pad1 = __uint_as_float((uint32_t)(tracked >> 32));
         P.tile_out[pose * (size_t)P.n_tiles + tile] = t;
+    }
     }
 }
 
@@ -253,7 +273,11 @@ __device__ __forceinline__ v2f pk_sub_hi(v2f a, v2f b) {
 // table value.  This is what the pairs that the f32 test cannot decide go through (queued by the
 // pair loop, done after it), and all pairs of a wave whose queue overflowed.
 struct ExactCtx {
-    const double *rx, *ry, *rz;  // this pose's receptor f64 coordinates (tile order)
+    const double *rx, *ry, *rz;  // receptor f64 coordinates (tile order), undeformed
+    const double *modes;         // receptor ANM modes [mode][xyz][pad] and this pose's amplitudes, or num_anm = 0
+    const double *rec_nm;
+    size_t pad;
+    int num_anm;
     const uint32_t *rec_tindex;
     const int32_t *rec_slot, *lig_slot;
     const double *step4;         // LDS: 4 * bin_step[]
@@ -264,7 +288,15 @@ struct ExactCtx {
 };
 __device__ __forceinline__ double exact_pair(const ExactCtx &c, const Vec3 &p, uint32_t lig_term, int la, int ra, uint32_t &in_cutoff) {
     // (2 x_rec - 2 x_lig)^2 + ... = 4 d2 bit for bit (power-of-two scaling commutes with rounding)
-    const double dx = 2.0 * c.rx[ra] - 2.0 * p.x, dy = 2.0 * c.ry[ra] - 2.0 * p.y, dz = 2.0 * c.rz[ra] - 2.0 * p.z;
+    double rx = c.rx[ra], ry = c.ry[ra], rz = c.rz[ra];
+    for (int k = 0; k < c.num_anm; k++) {  // src/dfire.rs:304-320, the same operations as dfire_packed_prepare
+        const double a = c.rec_nm[k];
+        const double *m = c.modes + (size_t)k * 3 * c.pad;
+        rx += m[ra] * a;
+        ry += m[c.pad + ra] * a;
+        rz += m[2 * c.pad + ra] * a;
+    }
+    const double dx = 2.0 * rx - 2.0 * p.x, dy = 2.0 * ry - 2.0 * p.y, dz = 2.0 * rz - 2.0 * p.z;
     const double D = dx * dx + dy * dy + dz * dz;
     if (!(D <= kCutScaled)) return 0.0;  // d2 <= 225 (src/dfire.rs:334)
     uint32_t bin = 0;  // src/dfire.rs:336-337 as a count of the steps passed
@@ -287,11 +319,14 @@ __device__ __forceinline__ bool beyond_cutoff_slot(uint32_t byte_offset) {
     return (d % kTiledRecStride) / kTiledPatchDoubles == 5u && (d % 4u) == 1u;
 }
 
-#ifndef LD_PACKED_MIN_BLOCKS
-#define LD_PACKED_MIN_BLOCKS (32 / kPackedWaves)  // 8 waves per SIMD: at most 64 VGPRs
+// Second argument of __launch_bounds__ in HIP: waves per SIMD the register allocation must allow.  One-wave
+// workgroups: the LUT in LDS limits the CU to 24 (unit cells) or 14 (half-unit cells) waves anyway, and the
+// kernel runs equally fast at 3 to 6 waves per SIMD, so it gets the registers it asks for.
+#ifndef LD_PACKED_WAVES_PER_SIMD
+#define LD_PACKED_WAVES_PER_SIMD (kPackedWaves == 1 ? (SC == 1 ? 5 : 3) : 8)
 #endif
 template <bool COUNT, int SC>
-__global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_MIN_BLOCKS) void dfire_packed_pairs(const PackedLaunch T) {
+__global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void dfire_packed_pairs(const PackedLaunch T) {
     // separate LDS objects: the backend tells the LDS-DMA target apart from the other arrays
     __shared__ __attribute__((aligned(16))) uint32_t s_lut[kPackedLutCells * SC];
     __shared__ __attribute__((aligned(16))) double s_step4[kDfireSteps];
@@ -541,9 +576,13 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_MIN_BLOCKS) void dfire
 
         // ---- 4b. the pairs the f32 test could not decide, in f64 --------------------------------------
         ExactCtx ex;
-        ex.rx = T.rec.x + pose * T.rec.pose_stride_xyz;
-        ex.ry = T.rec.y + pose * T.rec.pose_stride_xyz;
-        ex.rz = T.rec.z + pose * T.rec.pose_stride_xyz;
+        ex.rx = T.rec.x;
+        ex.ry = T.rec.y;
+        ex.rz = T.rec.z;
+        ex.modes = T.rec.modes;
+        ex.rec_nm = row + 7;
+        ex.pad = (size_t)T.rec.n_tiles * 64;
+        ex.num_anm = T.rec.num_anm;
         ex.rec_tindex = T.rec.tindex;
         ex.rec_slot = T.rec.slot;
         ex.lig_slot = T.lig.slot;
@@ -652,7 +691,7 @@ hipError_t launch_dfire_packed(const PackedLaunch &t, hipStream_t stream) {
 
 hipError_t launch_packed_prepare(const PackedPrepareLaunch &p, hipStream_t stream) {
     if (p.n_poses == 0 || p.n_tiles == 0) return hipSuccess;
-    const size_t blocks = p.n_poses * (size_t)p.n_tiles;
+    const size_t blocks = ((p.n_poses + kPreparePoses - 1) / kPreparePoses) * (size_t)p.n_tiles;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(dfire_packed_prepare, dim3((unsigned)blocks), dim3(64), 0, stream, p);
     return hipGetLastError();

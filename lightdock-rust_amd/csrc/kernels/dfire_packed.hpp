@@ -84,10 +84,12 @@ struct PackedReceptor {
     const PackedRecPair *pairs = nullptr;       // [n_tiles*32]
     const TiledBox *sub_boxes = nullptr;        // [n_tiles*8], scaled + centred frame
     const TiledBox *tile_boxes = nullptr;       // [n_tiles]; pad0/pad1 = bit per atom of the tile that has a flag slot
-    const double *x = nullptr, *y = nullptr, *z = nullptr;  // f64, tile order, padded: the exact path reads these
+    const double *x = nullptr, *y = nullptr, *z = nullptr;  // f64, tile order, padded, undeformed: the exact path reads these ...
+    const double *modes = nullptr;              // ... and deforms them itself when the image is per pose: [mode][xyz][n_tiles*64]
+    int num_anm = 0;                            // 0 = static image
     const int32_t *slot = nullptr;              // tile order
     const uint32_t *tindex = nullptr;           // tile order: tiled_rec_term(type), what the records carry
-    size_t pose_stride_pairs = 0, pose_stride_sub = 0, pose_stride_tile = 0, pose_stride_xyz = 0;  // 0 = static image
+    size_t pose_stride_pairs = 0, pose_stride_sub = 0, pose_stride_tile = 0;  // 0 = static image
     int flag_words = 0;
 };
 
@@ -139,7 +141,6 @@ struct PackedPrepareLaunch {
     float ubound = 0.f;
     PackedRecPair *pairs_out = nullptr;
     TiledBox *sub_out = nullptr, *tile_out = nullptr;
-    double *xyz_out = nullptr;  // [pose][3][n_tiles*64] deformed f64 coordinates, or nullptr (static image: the inputs are it)
 };
 
 // Bound on |D_f32 - 4 d2| (units of 4 d2) for two records inside `ubound` (record units) whose true

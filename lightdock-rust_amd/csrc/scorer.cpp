@@ -579,16 +579,15 @@ void Scorer::build_packed(const ld_scorer_desc &desc) {
         p.pairs_out = pairs;
         p.sub_out = sub;
         p.tile_out = tile;
-        p.xyz_out = nullptr;
         hip_check(launch_packed_prepare(p, stream_), "launch dfire_packed_prepare");
         hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
         P.rec.pairs = pairs;
         P.rec.sub_boxes = sub;
         P.rec.tile_boxes = tile;
-        P.rec.x = tiled_rec_soa_.x;
-        P.rec.y = tiled_rec_soa_.y;
-        P.rec.z = tiled_rec_soa_.z;
     }
+    P.rec.x = tiled_rec_soa_.x;  // undeformed; the exact path applies the modes of a per-pose image itself
+    P.rec.y = tiled_rec_soa_.y;
+    P.rec.z = tiled_rec_soa_.z;
     use_packed_ = true;
 }
 
@@ -650,7 +649,6 @@ Scorer::~Scorer() {
     ws_rec_sub_.release();
     ws_rec_tile_.release();
     ws_rec_pairs_.release();
-    ws_rec_xyz_.release();
     ws_exact_.release();
     ws_poses_.release();
     ws_energies_.release();
@@ -658,7 +656,7 @@ Scorer::~Scorer() {
 
 uint64_t Scorer::workspace_generation() const {
     return ws_partial_.generation + ws_flags_.generation + ws_counts_.generation + ws_tested_.generation + ws_exact_.generation +
-           ws_rec_atoms_.generation + ws_rec_sub_.generation + ws_rec_tile_.generation + ws_rec_pairs_.generation + ws_rec_xyz_.generation;
+           ws_rec_atoms_.generation + ws_rec_sub_.generation + ws_rec_tile_.generation + ws_rec_pairs_.generation;
 }
 
 void Scorer::reserve_workspace(size_t n_poses, bool counts) {
@@ -682,7 +680,7 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
         // every pose carries its own deformed receptor image: bound that workspace (8 GiB) by
         // slicing very large batches; poses are independent, so the results do not change
         const size_t pad = (size_t)tiled_.rec.n_tiles * 64;
-        const size_t per_pose = (use_packed_ ? pad / 2 * sizeof(PackedRecPair) + 3 * pad * sizeof(double) : pad * sizeof(TiledAtom)) +
+        const size_t per_pose = (use_packed_ ? pad / 2 * sizeof(PackedRecPair) : pad * sizeof(TiledAtom)) +
                                 (pad / 8 + pad / 64) * sizeof(TiledBox);
         static const size_t cap = [] {  // LIGHTDOCK_RECEPTOR_IMAGE_MIB: test hook for the slicing
             const char *e = std::getenv("LIGHTDOCK_RECEPTOR_IMAGE_MIB");
@@ -746,25 +744,21 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
         if (rec_anm_per_pose_) {  // one deformed receptor image per pose (src/dfire.rs:304-320)
             const size_t pad = (size_t)t.rec.n_tiles * 64;
             ws_rec_pairs_.reserve(n * (pad / 2) * sizeof(PackedRecPair));
-            ws_rec_xyz_.reserve(n * 3 * pad * sizeof(double));
             ws_rec_sub_.reserve(n * (pad / 8) * sizeof(TiledBox));
             ws_rec_tile_.reserve(n * (pad / 64) * sizeof(TiledBox));
             PackedPrepareLaunch pr = packed_prepare_launch(d_poses, stride, d_active, n);
             pr.pairs_out = static_cast<PackedRecPair *>(ws_rec_pairs_.ptr);
-            pr.xyz_out = static_cast<double *>(ws_rec_xyz_.ptr);
             pr.sub_out = static_cast<TiledBox *>(ws_rec_sub_.ptr);
             pr.tile_out = static_cast<TiledBox *>(ws_rec_tile_.ptr);
             hip_check(launch_packed_prepare(pr, stream_), "launch dfire_packed_prepare");
             t.rec.pairs = pr.pairs_out;
             t.rec.sub_boxes = pr.sub_out;
             t.rec.tile_boxes = pr.tile_out;
-            t.rec.x = pr.xyz_out;
-            t.rec.y = pr.xyz_out + pad;
-            t.rec.z = pr.xyz_out + 2 * pad;
+            t.rec.modes = pr.modes;
+            t.rec.num_anm = pr.num_anm;
             t.rec.pose_stride_pairs = pad / 2;
             t.rec.pose_stride_sub = pad / 8;
             t.rec.pose_stride_tile = pad / 64;
-            t.rec.pose_stride_xyz = 3 * pad;
         }
         hip_check(launch_dfire_packed(t, stream_), "launch dfire_packed_pairs");
     } else     if (use_tiled_) {

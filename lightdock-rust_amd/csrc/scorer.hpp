@@ -136,7 +136,7 @@ class Scorer {
     TiledLaunch tiled_;
     bool use_packed_ = false;  // DFIRE default: culling + packed-f32 pair test with exact f64 path (kernels/dfire_packed.hpp)
     PackedLaunch packed_;
-    DeviceBuffer ws_rec_pairs_, ws_rec_xyz_, ws_exact_;
+    DeviceBuffer ws_rec_pairs_, ws_exact_;
     TiledSoA tiled_rec_soa_;          // receptor in tile order (input of dfire_prepare_receptor)
     bool rec_anm_per_pose_ = false;   // receptor ANM: one receptor image per pose per launch
     DeviceBuffer ws_rec_atoms_, ws_rec_sub_, ws_rec_tile_;

@@ -82,7 +82,6 @@ hipError_t launch_packed_prepare(const PackedPrepareLaunch &p, hipStream_t) {
     if (p.n_poses && p.pairs_out) std::memset(p.pairs_out, 0, p.n_poses * (size_t)p.n_tiles * 32 * sizeof(PackedRecPair));
     if (p.n_poses && p.sub_out) std::memset(p.sub_out, 0, p.n_poses * (size_t)p.n_tiles * 8 * sizeof(TiledBox));
     if (p.n_poses && p.tile_out) std::memset(p.tile_out, 0, p.n_poses * (size_t)p.n_tiles * sizeof(TiledBox));
-    if (p.n_poses && p.xyz_out) std::memset(p.xyz_out, 0, p.n_poses * 3 * (size_t)p.n_tiles * 64 * sizeof(double));
     return hipSuccess;
 }
 size_t gso_kernel_lds_bytes(const GsoLaunch &) { return 0; }

@@ -37,7 +37,7 @@ def bin_of(d2):
     b = b + (d2 >= steps[np.minimum(b+1, 20)])   # exact step
     return b
 numberings = {"reference type numbers": (lt, rt), "types paired per molecule (library)": (PERMS[id(lig)][lt], PERMS[id(rec)][rt])}
-shapes = [(1,1,16),(1,16,1),(1,8,2),(1,4,4),(2,8,1),(4,4,1),(2,4,2),(4,2,2),(2,2,4),(4,1,4),(8,1,2),(1,8,1),(2,2,2),(1,1,8),(2,4,4),(4,4,4)]
+shapes = [(1,1,16),(1,16,1),(1,8,2),(1,4,4),(2,8,1),(4,4,1),(2,4,2),(4,2,2),(2,2,4),(4,1,4),(8,1,2),(2,1,8),(1,2,8),(1,8,1),(2,2,2),(1,1,8),(2,4,4),(4,4,4)]
 counts = {(k, sh): 0 for k in numberings for sh in shapes}
 hits_total = 0; blocks_total = 0
 for p in pos[::25]:
