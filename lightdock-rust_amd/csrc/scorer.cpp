@@ -456,7 +456,12 @@ double dfire_f32_error_bound(double ubound, int cells_per_unit) {
 
 // The cell LUT of the packed DFIRE kernel (kernels/dfire_packed.hpp) for `sc` cells per unit of
 // 4 d2 and an f32 distance error of at most `eps` (units of 4 d2).
-std::vector<uint32_t> build_packed_lut(int sc, double eps) {
+//
+// `zero_bins`: bit b set = the potential is 0.0 in bin b for every (receptor type, ligand type) of this
+// complex (DFIRE's reference state makes the last shell before the cutoff exactly that).  A cell whose
+// pairs can only land in such bins reads "miss": the sum does not change by a bit (x + 0.0 = x) and the
+// pair costs no table line.  Cells that may set interface flags are left alone.
+std::vector<uint32_t> build_packed_lut(int sc, double eps, uint32_t zero_bins) {
     // cell LUT.  Cell k holds the pairs with D' = sc * 4 d2 + 1/2 (f32) in [k, k+1), i.e. a true
     // 4 d2 within ((k - 1/2) / sc - eps, (k + 1/2) / sc + eps); the last cell everything further.
     const DfireBinning b = build_dfire_binning();
@@ -487,7 +492,7 @@ std::vector<uint32_t> build_packed_lut(int sc, double eps) {
         if (!code && !below_iface) {
             if (dfire_bin_reference(std::max(ilo, 0.0) / 4.0) != base_bin || dfire_bin_reference(ihi / 4.0) != base_bin)
                 throw Error(LD_ERR_INVALID, "DFIRE cell LUT self-check failed in cell " + std::to_string(k));
-            words[k] = tiled_bin_term((uint32_t)base_bin);
+            words[k] = (zero_bins >> base_bin) & 1u ? kPackedMiss : tiled_bin_term((uint32_t)base_bin);
             continue;
         }
         // Lean form: the only step of the cell sits at its middle (the squares (n+1)^2 are integers;
@@ -499,9 +504,14 @@ std::vector<uint32_t> build_packed_lut(int sc, double eps) {
         const uint32_t flags_code = below_iface ? kPackedCodeFlags : 0u;
         if (code == 0) {  // below the interface distance, no step: lean with nothing to grow by
             words[k] = kPackedSlow | ((kPackedCodeLean | flags_code) << 24) | tiled_bin_term((uint32_t)base_bin);
+        } else if (code == kPackedCodeStep && mid && !below_iface && ((zero_bins >> base_bin) & 3u) == 3u) {
+            words[k] = kPackedMiss;  // zero on both sides of the step
         } else if (code == kPackedCodeStep && mid) {
             const uint32_t below = tiled_bin_term((uint32_t)base_bin);
             words[k] = kPackedSlow | ((kPackedCodeLean | flags_code) << 24) | ((tiled_bin_term((uint32_t)base_bin + 1) - below) << 12) | below;
+        } else if (code == (kPackedCodeStep | kPackedCodeCutoff) && mid && std::fabs(step_at - 900.0) <= 1e-9 && base_bin == 19 &&
+                   ((zero_bins >> 19) & 3u) == 3u) {
+            words[k] = kPackedMiss;  // bins 19 and 20 are zero: nothing to read on either side of the cutoff
         } else if (code == (kPackedCodeStep | kPackedCodeCutoff) && mid && std::fabs(step_at - 900.0) <= 1e-9 && base_bin == 19) {
             // beyond the cutoff = the unused bin slot 21 of the same patch group, which holds 0.0
             const uint32_t below = tiled_bin_term(19u);
@@ -558,7 +568,28 @@ void Scorer::build_packed(const ld_scorer_desc &desc) {
     P.bin_step = pair_.bin_step;
     P.iface_scaled = 4.0 * pair_.iface_d2;
 
-    P.lut = arena_.upload(build_packed_lut(sc, (double)P.eps));
+    // bins in which this complex's potential is zero throughout (bin 20 = the read past the row at r = 15.0)
+    uint32_t zero_bins = 0;
+    {
+        const char *e = std::getenv("LIGHTDOCK_PACKED_ELIDE_ZERO_BINS");
+        if (!(e && std::strcmp(e, "0") == 0)) {
+            std::vector<char> rec_has(169, 0), lig_has(169, 0);
+            for (size_t i = 0; i < desc.receptor.n_atoms; i++) rec_has[desc.receptor.dfire_types[i]] = 1;
+            for (size_t i = 0; i < desc.ligand.n_atoms; i++) lig_has[desc.ligand.dfire_types[i]] = 1;
+            for (uint32_t b = 0; b <= 20; b++) {
+                bool all_zero = true;
+                for (uint32_t r = 0; r < 169 && all_zero; r++)
+                    for (uint32_t l = 0; l < 169 && all_zero; l++)
+                        if (rec_has[r] && lig_has[l] && (size_t)r * kDfireRowStride + l * 20 + b < LD_DFIRE_TABLE_LEN &&
+                            desc.potential[(size_t)r * kDfireRowStride + l * 20 + b] != 0.0)
+                            all_zero = false;
+                if (all_zero) zero_bins |= 1u << b;
+            }
+        }
+    }
+    packed_zero_bins_ = zero_bins;
+    P.lut = arena_.upload(build_packed_lut(sc, (double)P.eps, zero_bins));
+    packed_lut_full_ = zero_bins ? arena_.upload(build_packed_lut(sc, (double)P.eps, 0)) : P.lut;  // counting launches count every pair
 
     int split = tiled_.split;
     P.split = split;
@@ -738,6 +769,7 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
         t.partial = p.partial;
         t.flags = p.flags;
         t.count_partial = p.count_partial;
+        if (p.count_partial) t.lut = packed_lut_full_;
         t.tested_partial = p.count_partial ? static_cast<uint32_t *>(ws_tested_.ptr) : nullptr;
         t.exact_partial = p.count_partial ? static_cast<uint32_t *>(ws_exact_.ptr) : nullptr;
         p.n_chunks = t.n_groups * kPackedPartialsPerGroup;  // the tail kernel folds this many partials

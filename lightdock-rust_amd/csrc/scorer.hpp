@@ -63,7 +63,7 @@ struct DfireBinning {
 };
 DfireBinning build_dfire_binning();                  // throws if the self-check fails
 double dfire_interface_d2();                         // largest d2 with sqrt(d2)*2-1 <= 3.9
-std::vector<uint32_t> build_packed_lut(int cells_per_unit, double eps);  // kPackedLutCells * cells_per_unit words
+std::vector<uint32_t> build_packed_lut(int cells_per_unit, double eps, uint32_t zero_bins = 0);  // kPackedLutCells * cells_per_unit words
 
 class Scorer {
    public:
@@ -136,6 +136,8 @@ class Scorer {
     TiledLaunch tiled_;
     bool use_packed_ = false;  // DFIRE default: culling + packed-f32 pair test with exact f64 path (kernels/dfire_packed.hpp)
     PackedLaunch packed_;
+    const uint32_t *packed_lut_full_ = nullptr;  // the LUT without elided zero bins (counting launches)
+    uint32_t packed_zero_bins_ = 0;
     DeviceBuffer ws_rec_pairs_, ws_exact_;
     TiledSoA tiled_rec_soa_;          // receptor in tile order (input of dfire_prepare_receptor)
     bool rec_anm_per_pose_ = false;   // receptor ANM: one receptor image per pose per launch

@@ -345,6 +345,43 @@ def test_dfire_kernel_variants_agree(pkg, orc, table, scorers, name, env):
     assert np.array_equal(counts[0][:16].astype(np.int64), stats.astype(np.int64))
 
 
+@pytest.mark.parametrize("name", ["1ppe", "1k4c", "2uuy"])
+@pytest.mark.parametrize("zeroed", [(19,), (17, 18, 19), (5, 19)])
+def test_bins_that_are_zero_for_the_whole_complex_are_not_read(pkg, orc, table, name, zeroed, monkeypatch):
+    """A potential that is 0.0 in a bin for every type pair of the complex (DFIRE's reference state does
+    that to the last shell) lets the default kernel skip the table for the pairs of that bin.  The sums
+    must equal those of the same kernel reading the zeros (to rounding: the pairs that go through the
+    exact path are folded by other lanes when the queue holds fewer of them), the oracle must agree, and
+    the in-cutoff pair counts still count every pair."""
+    torch = pytest.importorskip("torch")
+    t = table.copy()
+    for b in zeroed:
+        t.reshape(169, 169, 20)[:, :, b] = 0.0
+    method, rec, lig, kw = case_kwargs(name, orc, t)
+    skipping = pkg.Scorer.from_pdb(method, rec, lig, **kw)
+    monkeypatch.setenv("LIGHTDOCK_PACKED_ELIDE_ZERO_BINS", "0")
+    reading = pkg.Scorer.from_pdb(method, rec, lig, **kw)
+    monkeypatch.delenv("LIGHTDOCK_PACKED_ELIDE_ZERO_BINS")
+    cpu = orc.Scorer(method, rec, lig, **kw)
+    poses = case_positions(name, orc)[:64]
+    got = skipping.energy_batch(poses)
+    assert rel_err(got, reading.energy_batch(poses)) < 1e-12
+    assert rel_err(got, cpu.energy_rows(poses)) < REL_TOL
+    dev = torch.device("cuda:0")
+    d_poses = torch.from_numpy(poses).to(dev)
+    counts = []
+    for s in (skipping, reading):
+        d_out = torch.zeros(64, dtype=torch.float64, device=dev)
+        d_cnt = torch.zeros(64, dtype=torch.int32, device=dev)
+        s.energy_batch_device(64, d_poses.data_ptr(), poses.shape[1], d_out.data_ptr(), None, d_cnt.data_ptr())
+        torch.cuda.synchronize()
+        counts.append(d_cnt.cpu().numpy())
+        assert rel_err(d_out.cpu().numpy(), got) < 1e-12     # the counting launch reads the full LUT: same sums again
+    assert np.array_equal(counts[0], counts[1])
+    stats = np.array([cpu.energy_ex_row(p)[1][5] for p in poses[:8]])
+    assert np.array_equal(counts[0][:8].astype(np.int64), stats.astype(np.int64))
+
+
 def test_gso_run_graph_replay_equals_stepping(pkg, scorers, orc, monkeypatch):
     """ld_gso_run with LIGHTDOCK_GSO_GRAPH=1 (captured hipGraph, two steps per replay) == ld_gso_step repeated == oracle."""
     monkeypatch.setenv("LIGHTDOCK_GSO_GRAPH", "1")
