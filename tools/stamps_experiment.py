@@ -1,5 +1,5 @@
 """Where a wave of the tiled DFIRE kernel spends its time (s_memtime stamps summed over all waves).
-Needs lib/variants/stamps.so: bash tools/build_stamps_variant.sh (here), then run this on the GPU box."""
+Needs lib/variants/stamps.so: bash tools/build_variant.sh stamps -DLD_PACKED_STAMPS (here), then run this on the GPU box."""
 import sys, os, ctypes as C, numpy as np, shutil
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, root)
 L = os.path.join(root, "lightdock-rust_amd", "lib")
