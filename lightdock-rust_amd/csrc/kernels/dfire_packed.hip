@@ -2,7 +2,7 @@
 // (gfx950 / MI355X).  Interface and numerics: dfire_packed.hpp.
 //
 // Shape: "ligand tile stationary, receptor tiles streamed", as dfire_tiled.hip.
-//   wave64 = (pose, ligand tile of 64 atoms); 4 waves of one pose per workgroup.
+//   wave64 = workgroup = (pose, ligand tile of 64 atoms)  (kPackedWaves = 1, see dfire_packed.hpp).
 //   1. The wave poses its 64 ligand atoms in f64 (q v q^-1 + t, then ANM; src/dfire.rs:282-302),
 //      parks 16-byte f32 records {u, type term} in its LDS slice and builds 8 subtile boxes + the
 //      tile box with butterflies.
@@ -15,7 +15,8 @@
 //      3 packed subtractions and 3 packed fmas; per pair: convert, clamp, LUT word, offset,
 //      gather from the 2 x 2 x 4-patch table (out-of-range offset = 0.0 without a memory
 //      request), f64 add one trip later.
-//   5. wave64 shuffle reduction; one partial per (pose, workgroup).
+//   5. The pairs the f32 test could not decide are recomputed in f64 from the queue; wave64 shuffle
+//      reduction; one partial per (pose, workgroup), folded by pose_energy_finish.
 // Compiled with -ffp-contract=off: every f64 operation is the reference's; the f32 filter uses
 // explicit fmas.  No MFMA (lookup/reduction).
 #include "dfire_packed.hpp"
@@ -376,9 +377,6 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
     const int bj = lane & 7;                                 // box tests: lane = ligand subtile (lane >> 3) x receptor subtile bj
     const int ph = lane >> 5, pi = (lane >> 2) & 7, pq = lane & 3;  // pair loop: block of the trip, ligand atom, record
     double acc = 0.0, pend0 = 0.0, pend1 = 0.0;
-#ifdef LD_PACKED_DEPTH2
-    double pendB0 = 0.0, pendB1 = 0.0;
-#endif
     uint32_t cnt = 0, tested = 0, n_exact = 0;
     const uint32_t half_shift = (uint32_t)ph * 32u;
     uint32_t queued = 0;  // wave-uniform; beyond kPackedQueue the wave redoes its tile in f64 (overflow pass)
@@ -552,17 +550,9 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
 #endif
                     // retire the previous trip's gathers only now (their L2 latency hides behind
                     // this trip's LDS reads and arithmetic), then issue this trip's
-#ifdef LD_PACKED_DEPTH2
-                    acc += pendB0;
-                    acc += pendB1;
-                    asm volatile("" : "+v"(acc) : : "memory");
-                    pendB0 = pend0;
-                    pendB1 = pend1;
-#else
                     acc += pend0;
                     acc += pend1;
                     asm volatile("" : "+v"(acc) : : "memory");
-#endif
 #ifndef LD_PACKED_NO_GATHER
                     pend0 = table_entry(table, off0);
                     pend1 = table_entry(table, off1);
@@ -597,10 +587,6 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
             acc = 0.0;
             pend0 = 0.0;
             pend1 = 0.0;
-#ifdef LD_PACKED_DEPTH2
-            pendB0 = 0.0;
-            pendB1 = 0.0;
-#endif
             cnt = 0;
             const Vec3 p = pose_ligand_atom(T.lig, T.use_anm, T.anm_rec, row, la);
             const uint32_t lig_term = T.lig.tindex[la];
@@ -624,10 +610,6 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
         }
     }
 
-#ifdef LD_PACKED_DEPTH2
-    acc += pendB0;
-    acc += pendB1;
-#endif
     // ---- 5. reduction ----------------------------------------------------------------------------
     LD_STAMP(if (lane == 0) {
         atomicAdd(&g_ld_stamps[0], __builtin_amdgcn_s_memtime() - ts0);
