@@ -46,6 +46,7 @@ HBM_PEAK_GBS = 8000.0                      # MI355X HBM3E, /opt/skills/guides/MI
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one vector op per lane per cycle
 L2_PEAK_GBS = 34500.0                      # aggregate L2 bandwidth, same guide ("L2 (per XCD)": ~34.5 TB/s)
 L2_REQUEST_BYTES = 128                     # one TCP_TCC_READ_REQ = one 128-byte line (tools/microbench/l2_request_size.py)
+L2_GATHER_CEILING_GBS = 25300.0            # what the L2s deliver to random 128-byte lines (profiles/r02_l2_gather_ceiling.txt)
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
@@ -330,7 +331,9 @@ def main():
             rate = L2_REQUEST_BYTES * prof["l2_read_requests_per_launch"] / kern_s / 1e9
             l2 = {"bound": "L2 -> L1 fills (128-byte lines)", "achieved": rate, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": rate / L2_PEAK_GBS,
                   "l2_read_requests_per_launch": prof["l2_read_requests_per_launch"],
-                  "source": "TCP_TCC_READ_REQ_sum per launch of the pair kernel (profiles/), 128 bytes each"}
+                  "random_line_gather_ceiling": L2_GATHER_CEILING_GBS, "frac_of_gather_ceiling": rate / L2_GATHER_CEILING_GBS,
+                  "source": "TCP_TCC_READ_REQ_sum per launch of the pair kernel (profiles/), 128 bytes each; ceiling measured by "
+                            "tools/microbench/l2_gather.hip (profiles/r02_l2_gather_ceiling.txt)"}
         out = {
             "metric": "pose-energy evals/sec (%s, %s)" % (case["method"].upper(), args.workload),
             "value": total_evals / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
