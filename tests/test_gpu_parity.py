@@ -670,6 +670,44 @@ def test_receptor_anm_batch_slicing(pkg, scorers, orc, tmp_path):
     assert np.array_equal(np.load(tmp_path / "sliced.npy"), want)
 
 
+def test_receptor_anm_with_more_modes_than_the_image_kernel_keeps_in_registers(pkg, orc, table):
+    """The receptor-image kernel keeps 10 modes per atom in registers and reads any further ones per
+    pose; the exact path deforms its atoms by the same operations.  13 receptor modes, odd batch sizes
+    (the kernel takes 16 poses per wave), an active mask with holes, and a widened error band so that
+    hundreds of pairs go through the exact path."""
+    torch = pytest.importorskip("torch")
+    method, rec, lig, kw = case_kwargs("2uuy", orc, table)
+    rng = np.random.default_rng(11)
+    rec_modes = np.asarray(kw["rec_nmodes"], dtype=np.float64).reshape(10, -1)
+    extra = 0.05 * rng.standard_normal((3, rec_modes.shape[1]))
+    kw["rec_nmodes"] = np.concatenate([rec_modes, extra]).reshape(-1)
+    kw["rec_num_anm"] = 13
+    base = case_positions("2uuy", orc)
+    poses = np.concatenate([base[:, :17], rng.uniform(-1.0, 1.0, (len(base), 3)), base[:, 17:]], axis=1)[:83]
+    cpu = orc.Scorer(method, rec, lig, **kw)
+    want = cpu.energy_rows(poses)
+    for env in ({}, {"LIGHTDOCK_PACKED_EPS_SCALE": "8"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            hip = pkg.Scorer.from_pdb(method, rec, lig, **kw)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        assert rel_err(hip.energy_batch(poses), want) < REL_TOL
+        assert rel_err(hip.energy_batch(poses[:17]), want[:17]) < REL_TOL
+        dev = torch.device("cuda:0")
+        d_poses = torch.from_numpy(poses).to(dev)
+        active = (np.arange(len(poses)) % 3 != 1).astype(np.uint8)
+        d_active = torch.from_numpy(active).to(dev)
+        d_out = torch.full((len(poses),), 7.0, dtype=torch.float64, device=dev)
+        hip.energy_batch_device(len(poses), d_poses.data_ptr(), poses.shape[1], d_out.data_ptr(), d_active.data_ptr())
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        assert rel_err(got[active == 1], want[active == 1]) < REL_TOL
+        assert np.all(got[active == 0] == 7.0)
+
+
 @pytest.mark.timeout(900)
 def test_cli_100_steps_matches_reference_files_1azp(pkg, tmp_path):
     """The full published run of the example: 100 steps, all 11 gso files against the files the
