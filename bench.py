@@ -46,7 +46,8 @@ HBM_PEAK_GBS = 8000.0                      # MI355X HBM3E, /opt/skills/guides/MI
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: one vector op per lane per cycle
 L2_PEAK_GBS = 34500.0                      # aggregate L2 bandwidth, same guide ("L2 (per XCD)": ~34.5 TB/s)
 L2_REQUEST_BYTES = 128                     # one TCP_TCC_READ_REQ = one 128-byte line (tools/microbench/l2_request_size.py)
-L2_GATHER_CEILING_GBS = 25300.0            # what the L2s deliver to random 128-byte lines (profiles/r02_l2_gather_ceiling.txt)
+L2_GATHER_CEILING_GBS = 33300.0            # what the L2s deliver to a dense gather of random 128-byte lines of an L2-resident table;
+                                           # 25 300 when the lines are spread evenly over 5.5 MB (profiles/r02_l2_gather_ceiling.txt)
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 

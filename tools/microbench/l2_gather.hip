@@ -29,16 +29,17 @@ __global__ __launch_bounds__(64) void gather(const double *table, unsigned n_lin
     if (acc == 1.2345) out[0] = acc;
 }
 
-int main() {
-    const unsigned n_lines = 5500000 / 128;
+int main(int argc, char **argv) {
+    const unsigned n_lines = (argc > 1 ? (unsigned)(std::atof(argv[1]) * 1e6) : 5500000u) / 128;   // table size in MB
+    std::printf("table %.2f MB\n", n_lines * 128 / 1e6);
     std::vector<double> h((size_t)n_lines * 16, 1.0);
     double *table, *out;
     CHECK(hipMalloc(&table, h.size() * 8)); CHECK(hipMalloc(&out, 8));
     CHECK(hipMemcpy(table, h.data(), h.size() * 8, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const int iters = 2000;
-    for (int waves_per_cu : {8, 16, 24, 32}) {
-        for (int share : {1, 2, 3, 4, 8}) {
+    for (int waves_per_cu : {argc > 2 ? std::atoi(argv[2]) : 8, 24}) {
+        for (int share : {1, 2, 4}) {
             const int blocks = 256 * waves_per_cu;
             hipLaunchKernelGGL(gather, dim3(blocks), dim3(64), 0, 0, table, n_lines, 50, share, out);
             CHECK(hipEventRecord(e0));
