@@ -1,0 +1,125 @@
+// dfire_bm.hpp -- launch interface of the BLOCK-MAJOR DFIRE pose-energy path (K1, DFIRE, rigid molecules).
+//
+// Same sum as src/dfire.rs:325-345, same 64x64 / 8x8 box culling and the same f32-filter-with-exact-f64-path
+// numerics as dfire_packed.hpp, but the pair work is ordered by atom-pair BLOCK instead of by pose:
+//
+//   dfire_bm_pose    one thread per pose: the pose's rotation + translation as an f32 affine map into the record frame
+//   dfire_bm_cull    one wave per (pose, ligand tile): ligand atoms posed in f32, boxes, 64x64 and 8x8 box tests; every
+//                    surviving (ligand tile, receptor tile) pair of the pose becomes one ENTRY {pose, 64-bit block
+//                    mask} appended to that tile pair's list
+//   dfire_bm_pairs   one workgroup per (tile pair, ligand subtile a): for each of its 8 blocks (a, b) the 64 table
+//                    rows T[type_i][type_j][.] of the block are staged in LDS ONCE (dense L2 -> LDS copies), the
+//                    entries whose mask holds the block are compacted into batches of 64, and a batch runs lane = pose:
+//                    the lane poses the 8 ligand atoms of subtile a (uniform local coordinates, its pose's affine map)
+//                    and walks the 64 atom pairs of the block, whose receptor atoms and table rows are wave-uniform:
+//                    D'' = 64 d2 + 1/2 in packed f32, cell = (u32)D'', code = lut[cell] (u8, LDS), value = row[code]
+//                    (f64, LDS), f64 add.  No gather ever leaves the CU: the L2 -> L1 line fills that bound the
+//                    pose-major kernel (0.5 lines of 128 B per in-cutoff pair) are gone.
+//   dfire_bm_gather  one wave per pose: the pose's partial sums in a fixed order -> the [pose][1][2] partials that
+//                    pose_energy_finish folds (restraint / membrane tail, src/dfire.rs:347-361)
+//
+// Numerics: records are u = fl32(8 (x - c)); the ligand is posed by an f32 affine map whose error
+// is part of `eps`; a LUT cell (1/16 of a unit of 4 d2) whose interval, widened by eps, holds a bin step, the interface
+// distance or the cutoff is FLAGGED: its pairs read 0.0 and are recomputed in f64 (exact_pair, dfire_device.hpp) from
+// the f64 coordinates with the reference's quaternion posing.  Bins, cutoff decisions and interface flags are therefore
+// the reference's, bit for bit; the energies differ from the other kernels by summation order only, and -- the one
+// liberty this path takes -- the exact path's values reach the pose's sum through a 64-bit fixed-point accumulator
+// (2^-40 units) so that their order cannot matter.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "dfire_packed.hpp"
+
+namespace ld {
+
+constexpr int kBmCells = 16;                 // LUT cells per unit of 4 d2
+constexpr double kBmKappa = 8.0;             // records hold fl32(kappa (x - c)): D'' = sum (du)^2 = 16 * 4 d2
+constexpr int kBmCutCell = 900 * kBmCells;   // the cutoff 4 d2 = 900
+constexpr int kBmLutBytes = 14592;           // cells 0 .. 14591: everything beyond kBmCutCell + eps reads "miss"
+constexpr float kBmCellMax = 14591.0f;
+constexpr int kBmRowSlots = 22;              // slot 0 = 0.0 (miss), slot 1 + b = bin b (0..20; 20 = the read past the row at r = 15.0)
+constexpr int kBmRowBytes = kBmRowSlots * 8;
+constexpr int kBmCubeBytes = 64 * kBmRowBytes + 16;  // + one zero slot behind the last row
+constexpr uint32_t kBmFlagged = kBmRowBytes;  // LUT code of a flagged cell: slot 0 of the NEXT row = 0.0, above every bin code
+constexpr int kBmTypes = 170;                // 169 DFIRE types + one all-zero type for padding atoms
+constexpr int kBmWaves = 8;                  // waves per dfire_bm_pairs workgroup
+constexpr int kBmPartEntries = 4096;         // entries of a tile pair one workgroup walks (512 per wave)
+constexpr int kBmQueue = 256;                // per wave: pairs waiting for the exact path
+constexpr double kBmFixScale = 1099511627776.0;  // 2^40: fixed-point units of the exact path's sum
+
+struct BmModel {
+    // receptor (static image in the kappa = 8 frame; no receptor ANM on this path)
+    int rec_n_real = 0, rec_n_tiles = 0;
+    const PackedRecPair *rec_pairs = nullptr;   // [n_tiles*32]
+    const TiledBox *rec_sub = nullptr;          // [n_tiles*8]
+    const TiledBox *rec_tile = nullptr;         // [n_tiles]
+    const uint32_t *rec_rowoff = nullptr;       // [n_tiles*64]: byte offset of the atom's type column in a table row block
+    const double *rec_x = nullptr, *rec_y = nullptr, *rec_z = nullptr;  // f64, tile order (exact path)
+    const uint32_t *rec_tindex = nullptr;       // tile order: tiled_rec_term (exact path reads the patch table)
+    const int32_t *rec_slot = nullptr;
+    int rec_flag_words = 0;
+    // ligand
+    TiledLigand lig;                            // f64, tile order (exact path, overflow tiles)
+    const float *lig_local = nullptr;           // [n_tiles*64][4]: x, y, z (angstrom, f32), 1.0 = real atom
+    const uint32_t *lig_rowbase = nullptr;      // [n_tiles*64]: byte offset of the atom's type block in `rows`
+    // tables
+    const double *rows = nullptr;               // [kBmTypes lig][kBmTypes rec][kBmRowSlots]
+    const uint8_t *lut = nullptr;               // kBmLutBytes codes
+    const uint8_t *lut_full = nullptr;          // the same without elided zero bins (counting launches)
+    const double *table = nullptr;              // 2 x 2 x 4 patches (dfire_tiled.hpp): the exact path's table
+    const double *bin_step = nullptr;
+    double iface_scaled = 0.0;                  // 4 * iface_d2
+    double cx = 0, cy = 0, cz = 0;
+    float ubound = 0.f;                         // |u| beyond this: the atom is further than the cutoff from every receptor atom
+                                                // (the frame holds the receptor + 16 A) and joins no box
+    float box_pad = 0.f;                        // absolute widening of the ligand boxes (error of the f32 affine map)
+};
+
+struct BmLaunch {
+    BmModel m;
+    const double *poses = nullptr;
+    size_t stride = 0;
+    const uint8_t *active = nullptr;
+    const uint32_t *pose_list = nullptr;   // GSO: compacted rows + device-side count (both null for a plain batch)
+    const uint32_t *pose_count = nullptr;
+    size_t first = 0;                      // this launch covers listed rows [first, first + n_poses)
+    size_t n_poses = 0;
+    size_t cap = 0;                        // entries per tile pair the workspace has room for (>= n_poses)
+    // workspace
+    float *rt = nullptr;                   // [pose][12]
+    uint32_t *tp_count = nullptr;          // [n_tile_pairs], zeroed per launch
+    uint32_t *ent_pose = nullptr;          // [tile pair][cap]
+    unsigned long long *ent_mask = nullptr;  // [tile pair][cap]
+    double *ent_partial = nullptr;         // [tile pair][8][cap]
+    uint32_t *ent_count = nullptr;         // [tile pair][8][cap] or nullptr (counting launches)
+    uint32_t *vis_count = nullptr;         // [pose][lig tiles]
+    uint32_t *vis_entry = nullptr;         // [pose][lig tiles][rec tiles]: receptor tile << 24 | entry
+    uint32_t *tile_tested = nullptr;       // [pose][lig tiles]: 8x8 blocks let through (diagnostics) or nullptr
+    long long *exact_fix = nullptr;        // [pose], zeroed per launch: exact-path sum in 2^-40 units
+    uint32_t *exact_count = nullptr;       // [pose], zeroed per launch, or nullptr
+    uint32_t *exact_pairs = nullptr;       // [pose], zeroed: pairs recomputed in f64 (diagnostics) or nullptr
+    uint32_t *flags = nullptr;             // [pose][rec words + lig words], zeroed per launch
+    double *partial = nullptr;             // out: [pose][1][2] for pose_energy_finish
+    uint32_t *count_partial = nullptr;     // out: [pose][1] or nullptr
+    uint32_t *tested_partial = nullptr;    // out: [pose][1] or nullptr
+    uint32_t *exact_partial = nullptr;     // out: [pose][1] or nullptr
+};
+
+// Bound on |D''_f32 - 64 d2 - 1/2| (LUT cells) for a ligand atom posed by the f32 affine map and a receptor record,
+// both inside `ubound` (record units), pairs within 1100 units of 4 d2; `lig_extent` = largest |local coordinate| of
+// the ligand (angstrom).  Twice the derived bound.
+double dfire_bm_error_bound(double ubound, double lig_extent);
+// Largest distance (record units) between an f32-posed ligand atom inside ubound and its exactly posed position.
+double dfire_bm_pose_error(double ubound, double lig_extent);
+
+size_t bm_pairs_lds_bytes();
+hipError_t launch_bm_pose(const BmLaunch &t, hipStream_t stream);
+hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream);
+hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream);
+hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t stream);
+
+}  // namespace ld

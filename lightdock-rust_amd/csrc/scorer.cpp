@@ -301,6 +301,11 @@ Scorer::Scorer(const ld_scorer_desc &desc) {
         use_tiled_ = !(k && std::strcmp(k, "allpairs") == 0);
         if (use_tiled_) build_tiled(desc);
         if (use_tiled_ && !(k && std::strcmp(k, "tiled") == 0)) build_packed(desc);
+        // "bm" / default: the block-major path for rigid molecules (kernels/dfire_bm.hpp); "packed": the pose-major
+        // kernel for everything (what ANM runs and LIGHTDOCK_TILED_LATENCY=1, the single-swarm CLI, use anyway)
+        const char *latency = std::getenv("LIGHTDOCK_TILED_LATENCY");
+        if (use_packed_ && !(k && std::strcmp(k, "packed") == 0) && !(latency && std::atoi(latency) > 0 && !(k && std::strcmp(k, "bm") == 0)))
+            build_bm(desc);
     }
 }
 
@@ -333,6 +338,12 @@ void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, Tiled
     }
     out.n_real = (int)n;
     out.n_tiles = (int)(np / 64);
+    out.hx = x;
+    out.hy = y;
+    out.hz = z;
+    out.htype.assign(np, kPad);
+    for (size_t i = 0; i < np; i++)
+        if (order[i] != kPad) out.htype[i] = m.dfire_types[order[i]];
     out.x = arena_.upload(x);
     out.y = arena_.upload(y);
     out.z = arena_.upload(z);
@@ -354,7 +365,7 @@ void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, Tiled
 
 void Scorer::build_tiled(const ld_scorer_desc &desc) {
     upload_tiled_molecule(desc.receptor, true, tiled_rec_soa_);
-    TiledSoA lig;
+    TiledSoA &lig = tiled_lig_soa_;
     upload_tiled_molecule(desc.ligand, false, lig);
     tiled_.lig.n_real = lig.n_real;
     tiled_.lig.n_tiles = lig.n_tiles;
@@ -527,18 +538,8 @@ std::vector<uint32_t> build_packed_lut(int sc, double eps, uint32_t zero_bins) {
 // kernels/dfire_packed.hpp (every cell that cannot decide the reference's f64 result is flagged),
 // and the receptor image as pair records.
 void Scorer::build_packed(const ld_scorer_desc &desc) {
-    const ld_molecule &rec = desc.receptor;
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (size_t i = 0; i < rec.n_atoms; i++)
-        for (int c = 0; c < 3; c++) {
-            lo[c] = std::min(lo[c], rec.coordinates[3 * i + c]);
-            hi[c] = std::max(hi[c], rec.coordinates[3 * i + c]);
-        }
-    double centre[3], half = 0.0;
-    for (int c = 0; c < 3; c++) {
-        centre[c] = 0.5 * (lo[c] + hi[c]);
-        half = std::max(half, 0.5 * (hi[c] - lo[c]));
-    }
+    double centre[3], half;
+    frame_of_receptor(desc.receptor, centre, &half);
     // LUT cells per unit of 4 d2: 2 halves the share of pairs in flagged cells for 4 KiB more LDS
     int sc = kPackedWaves == 1 ? 1 : 2;  // one-wave workgroups: the LUT is per wave, the smaller one keeps 6 waves per SIMD
     if (const char *e = std::getenv("LIGHTDOCK_PACKED_CELLS")) sc = std::atoi(e) == 1 ? 1 : 2;
@@ -622,6 +623,221 @@ void Scorer::build_packed(const ld_scorer_desc &desc) {
     use_packed_ = true;
 }
 
+// ---------------------------------------------------------------------------------------
+// Block-major DFIRE path (kernels/dfire_bm.hpp)
+// ---------------------------------------------------------------------------------------
+double dfire_bm_pose_error(double ubound, double lig_extent) {
+    // u = fl32(kappa R) x_f32 + fl32(kappa (t - c)), three fmas.  Per coordinate, in record units:
+    //   matrix rounding            3 * 2^-24 * kappa * extent      (|kappa R_ij| <= kappa, |x| <= extent)
+    //   local coordinate rounding  3 * kappa * 2^-24 * extent
+    //   translation rounding + the three fma roundings (partial sums below 2 U): 4 * 2^-24 U
+    const double e = std::ldexp(6.0 * kBmKappa * lig_extent, -24) + std::ldexp(ubound, -22);
+    return std::sqrt(3.0) * e;
+}
+
+double dfire_bm_error_bound(double ubound, double lig_extent) {
+    const double e_lig = dfire_bm_pose_error(ubound, lig_extent) / std::sqrt(3.0);   // per coordinate
+    const double e_rec = std::ldexp(ubound, -25);
+    const double e_d = e_lig + e_rec + std::ldexp(256.0, -25);       // + the rounding of the difference (below 256 for pairs in range)
+    const double span = std::sqrt(3.0 * 1100.0 * kBmCells);          // |du| + |dv| + |dw| <= sqrt(3) |d|, pairs within 1100 units of 4 d2
+    const double eps = 2.0 * e_d * span + 3.0 * e_d * e_d + 3.0 * std::ldexp(32768.0, -25);   // + three fma roundings of sums below 32768
+    return 2.0 * eps;  // twice the bound, LUT cells
+}
+
+// Cell k holds the pairs with D'' = 64 d2 + 1/2 (f32) in [k, k + 1), i.e. a true 4 d2 within
+// ((k - 1/2 - eps) / 16, (k + 1/2 + eps) / 16).  A cell with ONE answer for that whole interval carries the bin's slot
+// in the block's table rows ((bin + 1) * 8; 0 = "miss" beyond the cutoff or a bin that is zero for the whole complex);
+// any other cell -- a bin step, the interface distance or the cutoff inside, or all of it below the interface distance
+// (src/dfire.rs:339: flags to set) -- is flagged: the kernel reads 0.0 and recomputes the pair in f64.
+std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins) {
+    const DfireBinning b = build_dfire_binning();
+    const double iface_scaled = 4.0 * dfire_interface_d2();
+    std::vector<uint8_t> codes(kBmLutBytes, 0);
+    for (int k = 0; k < kBmLutBytes; k++) {
+        const double ilo = (k - 0.5 - eps_cells) / kBmCells, ihi = (k + 0.5 + eps_cells) / kBmCells;
+        if (ilo > 900.0) continue;  // beyond the cutoff for sure
+        bool flagged = ihi >= 900.0 || ilo <= iface_scaled;
+        int base_bin = 0;
+        for (int s = 1; s <= 20; s++) {
+            const double at = 4.0 * b.step[s];
+            if (at < ilo) base_bin = s;
+            else if (at <= ihi) flagged = true;
+        }
+        if (flagged) {
+            codes[k] = (uint8_t)kBmFlagged;
+            continue;
+        }
+        if (dfire_bin_reference(std::max(ilo, 0.0) / 4.0) != base_bin || dfire_bin_reference(ihi / 4.0) != base_bin)
+            throw Error(LD_ERR_INVALID, "DFIRE block-major LUT self-check failed in cell " + std::to_string(k));
+        codes[k] = (zero_bins >> base_bin) & 1u ? 0 : (uint8_t)((base_bin + 1) * 8);
+    }
+    if (codes[kBmLutBytes - 1] != 0) throw Error(LD_ERR_INVALID, "DFIRE block-major LUT: the clamp cell is not a miss");
+    return codes;
+}
+
+void Scorer::frame_of_receptor(const ld_molecule &rec, double centre[3], double *half) const {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (size_t i = 0; i < rec.n_atoms; i++)
+        for (int c = 0; c < 3; c++) {
+            lo[c] = std::min(lo[c], rec.coordinates[3 * i + c]);
+            hi[c] = std::max(hi[c], rec.coordinates[3 * i + c]);
+        }
+    *half = 0.0;
+    for (int c = 0; c < 3; c++) {
+        centre[c] = 0.5 * (lo[c] + hi[c]);
+        *half = std::max(*half, 0.5 * (hi[c] - lo[c]));
+    }
+}
+
+void Scorer::build_bm(const ld_scorer_desc &desc) {
+    // rigid molecules only: with ANM the ligand's local coordinates (and the receptor image) change per pose
+    if (use_anm_ && (desc.receptor.num_anm > 0 || desc.ligand.num_anm > 0)) return;
+    if (rec_anm_per_pose_) return;
+    const TiledSoA &rec = tiled_rec_soa_, &lig = tiled_lig_soa_;
+    if (rec.n_tiles > 255 || lig.n_tiles > 4096) return;  // an entry names its receptor tile in 8 bits
+    double centre[3], half;
+    frame_of_receptor(desc.receptor, centre, &half);
+    // The frame holds the receptor's box + 16 A: a ligand atom outside it is beyond the cutoff of every receptor atom.
+    double ubound = 128.0;
+    while (ubound < kBmKappa * (half + 16.5)) ubound *= 2.0;
+    double extent = 0.0;
+    for (size_t i = 0; i < desc.ligand.n_atoms * 3; i++) extent = std::max(extent, std::fabs(desc.ligand.coordinates[i]));
+    double eps = dfire_bm_error_bound(ubound, extent);  // LUT cells
+    if (const char *e = std::getenv("LIGHTDOCK_PACKED_EPS_SCALE")) {  // test hook: results must not depend on it
+        const double f = std::atof(e);
+        if (f >= 1.0 && f <= 1000.0) eps *= f;
+    }
+    if (!(eps < 8.0)) return;  // a complex thousands of angstroms across: the pose-major kernels
+
+    BmModel &M = bm_;
+    M.rec_n_real = rec.n_real;
+    M.rec_n_tiles = rec.n_tiles;
+    M.rec_x = rec.x;
+    M.rec_y = rec.y;
+    M.rec_z = rec.z;
+    M.rec_tindex = rec.tindex;
+    M.rec_slot = rec.slot;
+    M.rec_flag_words = pair_.rec.flag_words;
+    M.lig = tiled_.lig;
+    M.cx = centre[0];
+    M.cy = centre[1];
+    M.cz = centre[2];
+    M.ubound = (float)ubound;
+    M.box_pad = std::nextafter((float)(2.0 * dfire_bm_pose_error(ubound, extent)), INFINITY);
+    M.table = tiled_.table;
+    M.iface_scaled = 4.0 * pair_.iface_d2;
+    {
+        const DfireBinning b = build_dfire_binning();
+        std::vector<double> step4(b.step);
+        for (double &v : step4) v *= 4.0;
+        M.bin_step = arena_.upload(step4);
+    }
+    M.lut = arena_.upload(build_bm_lut(eps, packed_zero_bins_));
+    M.lut_full = packed_zero_bins_ ? arena_.upload(build_bm_lut(eps, 0)) : M.lut;  // counting launches count every pair
+
+    {   // receptor image in this frame, by the kernel that builds the packed kernel's
+        const size_t pad = (size_t)rec.n_tiles * 64;
+        PackedRecPair *pairs = static_cast<PackedRecPair *>(arena_.alloc_bytes(pad / 2 * sizeof(PackedRecPair)));
+        TiledBox *sub = static_cast<TiledBox *>(arena_.alloc_bytes(pad / 8 * sizeof(TiledBox)));
+        TiledBox *tile = static_cast<TiledBox *>(arena_.alloc_bytes(pad / 64 * sizeof(TiledBox)));
+        PackedPrepareLaunch p = packed_prepare_launch(nullptr, 0, nullptr, 1);
+        p.num_anm = 0;
+        p.cx = centre[0];
+        p.cy = centre[1];
+        p.cz = centre[2];
+        p.kappa = kBmKappa;
+        p.ubound = (float)ubound;
+        p.pairs_out = pairs;
+        p.sub_out = sub;
+        p.tile_out = tile;
+        hip_check(launch_packed_prepare(p, stream_), "launch dfire_packed_prepare");
+        hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        M.rec_pairs = pairs;
+        M.rec_sub = sub;
+        M.rec_tile = tile;
+    }
+    const uint32_t kPad = std::numeric_limits<uint32_t>::max();
+    {   // per atom: where its type's rows / column sit in the row table; padding atoms take the all-zero type
+        std::vector<uint32_t> rowoff(rec.htype.size()), rowbase(lig.htype.size());
+        for (size_t i = 0; i < rowoff.size(); i++) rowoff[i] = (rec.htype[i] == kPad ? (uint32_t)kBmTypes - 1 : rec.htype[i]) * (uint32_t)kBmRowBytes;
+        for (size_t i = 0; i < rowbase.size(); i++)
+            rowbase[i] = (lig.htype[i] == kPad ? (uint32_t)kBmTypes - 1 : lig.htype[i]) * (uint32_t)(kBmTypes * kBmRowBytes);
+        M.rec_rowoff = arena_.upload(rowoff);
+        M.lig_rowbase = arena_.upload(rowbase);
+        std::vector<float> local(lig.htype.size() * 4, 0.f);
+        for (size_t i = 0; i < lig.htype.size(); i++) {
+            if (lig.htype[i] == kPad) continue;
+            local[4 * i] = (float)lig.hx[i];
+            local[4 * i + 1] = (float)lig.hy[i];
+            local[4 * i + 2] = (float)lig.hz[i];
+            local[4 * i + 3] = 1.f;
+        }
+        M.lig_local = arena_.upload(local);
+    }
+    {   // rows[l][r][0] = 0.0; rows[l][r][1 + b] = potential[r * 3380 + l * 20 + b], b = 0..20 (20 = the read past the row, src/dfire.rs:338)
+        std::vector<double> rows((size_t)kBmTypes * kBmTypes * kBmRowSlots, 0.0);
+        for (uint32_t l = 0; l < 169; l++)
+            for (uint32_t r = 0; r < 169; r++)
+                for (uint32_t b = 0; b <= 20; b++) {
+                    const size_t at = (size_t)r * kDfireRowStride + l * 20 + b;
+                    if (at < LD_DFIRE_TABLE_LEN) rows[((size_t)l * kBmTypes + r) * kBmRowSlots + 1 + b] = desc.potential[at];
+                }
+        M.rows = arena_.upload(rows);
+    }
+    // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x 76 bytes (108 with counts)
+    const size_t tile_pairs = (size_t)rec.n_tiles * lig.n_tiles;
+    size_t chunk = ((size_t)3 << 30) / (108 * tile_pairs);
+    chunk = std::max<size_t>(kBmPartEntries, chunk / kBmPartEntries * kBmPartEntries);
+    if (const char *e = std::getenv("LIGHTDOCK_BM_CHUNK")) {
+        const long v = std::atol(e);
+        if (v >= 1) chunk = (size_t)v;
+    }
+    bm_chunk_ = chunk;
+    use_bm_ = true;
+}
+
+void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_t *d_active, bool counts, const uint32_t *d_list,
+                    const uint32_t *d_count) {
+    const size_t tile_pairs = (size_t)bm_.lig.n_tiles * bm_.rec_n_tiles;
+    const size_t cap = std::min(n, bm_chunk_);
+    BmLaunch t;
+    t.m = bm_;
+    t.poses = d_poses;
+    t.stride = stride;
+    t.active = d_list ? nullptr : d_active;  // the list holds exactly the active rows
+    t.pose_list = d_list;
+    t.pose_count = d_list ? d_count : nullptr;
+    t.cap = cap;
+    t.rt = static_cast<float *>(ws_bm_rt_.ptr);
+    t.tp_count = static_cast<uint32_t *>(ws_bm_tp_count_.ptr);
+    t.ent_pose = static_cast<uint32_t *>(ws_bm_ent_pose_.ptr);
+    t.ent_mask = static_cast<unsigned long long *>(ws_bm_ent_mask_.ptr);
+    t.ent_partial = static_cast<double *>(ws_bm_ent_partial_.ptr);
+    t.vis_count = static_cast<uint32_t *>(ws_bm_vis_count_.ptr);
+    t.vis_entry = static_cast<uint32_t *>(ws_bm_vis_entry_.ptr);
+    t.exact_fix = static_cast<long long *>(ws_bm_exact_fix_.ptr);
+    t.flags = static_cast<uint32_t *>(ws_flags_.ptr);
+    t.partial = static_cast<double *>(ws_partial_.ptr);
+    if (counts) {
+        t.ent_count = static_cast<uint32_t *>(ws_bm_ent_count_.ptr);
+        t.tile_tested = static_cast<uint32_t *>(ws_bm_tile_tested_.ptr);
+        t.exact_count = static_cast<uint32_t *>(ws_bm_exact_count_.ptr);
+        t.exact_pairs = static_cast<uint32_t *>(ws_bm_exact_pairs_.ptr);
+        t.count_partial = static_cast<uint32_t *>(ws_counts_.ptr);
+        t.tested_partial = static_cast<uint32_t *>(ws_tested_.ptr);
+        t.exact_partial = static_cast<uint32_t *>(ws_exact_.ptr);
+    }
+    for (size_t off = 0; off < n; off += cap) {  // poses are independent: passes of at most `cap` poses
+        t.first = off;
+        t.n_poses = std::min(cap, n - off);
+        hip_check(hipMemsetAsync(t.tp_count, 0, tile_pairs * sizeof(uint32_t), stream_), "hipMemsetAsync(tile pair counts)");
+        hip_check(launch_bm_pose(t, stream_), "launch dfire_bm_pose");
+        hip_check(launch_bm_cull(t, stream_), "launch dfire_bm_cull");
+        hip_check(launch_bm_pairs(t, stream_), "launch dfire_bm_pairs");
+        hip_check(launch_bm_gather(t, stream_), "launch dfire_bm_gather");
+    }
+}
+
 PackedPrepareLaunch Scorer::packed_prepare_launch(const double *poses, size_t stride, const uint8_t *active, size_t n) const {
     PackedPrepareLaunch p;
     p.n_real = tiled_rec_soa_.n_real;
@@ -681,13 +897,19 @@ Scorer::~Scorer() {
     ws_rec_tile_.release();
     ws_rec_pairs_.release();
     ws_exact_.release();
+    for (DeviceBuffer *b : {&ws_bm_rt_, &ws_bm_tp_count_, &ws_bm_ent_pose_, &ws_bm_ent_mask_, &ws_bm_ent_partial_, &ws_bm_ent_count_, &ws_bm_vis_count_,
+                            &ws_bm_vis_entry_, &ws_bm_tile_tested_, &ws_bm_exact_fix_, &ws_bm_exact_count_, &ws_bm_exact_pairs_})
+        b->release();
     ws_poses_.release();
     ws_energies_.release();
 }
 
 uint64_t Scorer::workspace_generation() const {
     return ws_partial_.generation + ws_flags_.generation + ws_counts_.generation + ws_tested_.generation + ws_exact_.generation +
-           ws_rec_atoms_.generation + ws_rec_sub_.generation + ws_rec_tile_.generation + ws_rec_pairs_.generation;
+           ws_rec_atoms_.generation + ws_rec_sub_.generation + ws_rec_tile_.generation + ws_rec_pairs_.generation + ws_bm_rt_.generation +
+           ws_bm_tp_count_.generation + ws_bm_ent_pose_.generation + ws_bm_ent_mask_.generation + ws_bm_ent_partial_.generation +
+           ws_bm_ent_count_.generation + ws_bm_vis_count_.generation + ws_bm_vis_entry_.generation + ws_bm_tile_tested_.generation +
+           ws_bm_exact_fix_.generation + ws_bm_exact_count_.generation + ws_bm_exact_pairs_.generation;
 }
 
 void Scorer::reserve_workspace(size_t n_poses, bool counts) {
@@ -699,6 +921,24 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         ws_counts_.reserve(n_poses * chunks * sizeof(uint32_t));
         ws_tested_.reserve(n_poses * chunks * sizeof(uint32_t));
         ws_exact_.reserve(n_poses * chunks * sizeof(uint32_t));
+    }
+    if (use_bm_) {
+        const size_t n = n_poses, n_lt = (size_t)bm_.lig.n_tiles, n_rt = (size_t)bm_.rec_n_tiles, tile_pairs = n_lt * n_rt;
+        const size_t cap = std::min(n, bm_chunk_);
+        ws_bm_rt_.reserve(n * 12 * sizeof(float));
+        ws_bm_tp_count_.reserve(tile_pairs * sizeof(uint32_t));
+        ws_bm_ent_pose_.reserve(tile_pairs * cap * sizeof(uint32_t));
+        ws_bm_ent_mask_.reserve(tile_pairs * cap * sizeof(unsigned long long));
+        ws_bm_ent_partial_.reserve(tile_pairs * 8 * cap * sizeof(double));
+        ws_bm_vis_count_.reserve(n * n_lt * sizeof(uint32_t));
+        ws_bm_vis_entry_.reserve(n * tile_pairs * sizeof(uint32_t));
+        ws_bm_exact_fix_.reserve(n * sizeof(long long));
+        if (counts) {
+            ws_bm_ent_count_.reserve(tile_pairs * 8 * cap * sizeof(uint32_t));
+            ws_bm_tile_tested_.reserve(n * n_lt * sizeof(uint32_t));
+            ws_bm_exact_count_.reserve(n * sizeof(uint32_t));
+            ws_bm_exact_pairs_.reserve(n * sizeof(uint32_t));
+        }
     }
 }
 
@@ -758,7 +998,10 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
         }
         hip_check(hipEventRecord(events_[events_used_].first, stream_), "hipEventRecord");
     }
-    if (use_packed_) {
+    if (use_bm_) {
+        p.n_chunks = 1;  // dfire_bm_gather leaves one partial per pose
+        run_bm(n, d_poses, stride, d_active, d_pair_counts != nullptr, d_list, d_count);
+    } else if (use_packed_) {
         PackedLaunch t = packed_;
         t.poses = d_poses;
         t.stride = stride;
@@ -861,7 +1104,7 @@ void Scorer::energy_batch_host(size_t n, const double *poses, size_t stride, dou
 void Scorer::last_block_counts(size_t n, uint32_t *out_host) {
     if (!use_tiled_) throw Error(LD_ERR_UNSUPPORTED, "block counts exist for the tiled DFIRE kernel only");
     if (!out_host) throw Error(LD_ERR_INVALID, "null output");
-    const size_t groups = (size_t)(use_packed_ ? packed_.n_groups * kPackedPartialsPerGroup : tiled_.n_groups);
+    const size_t groups = (size_t)(use_bm_ ? 1 : use_packed_ ? packed_.n_groups * kPackedPartialsPerGroup : tiled_.n_groups);
     if (ws_tested_.bytes < n * groups * sizeof(uint32_t)) throw Error(LD_ERR_INVALID, "no counting launch of that size has run");
     std::vector<uint32_t> part(n * groups);
     hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
@@ -893,10 +1136,10 @@ void Scorer::pair_kernel_time(double *total_ms, uint64_t *launches) {
 }
 
 void Scorer::kernel_info(ld_kernel_info *out) const {
-    out->pair_kernel_name = use_packed_ ? "dfire_packed_pairs" : use_tiled_ ? "dfire_tiled_pairs" : pair_kernel_name(method_);
-    out->block_threads = use_packed_ ? (uint32_t)kPackedWaves * 64 : use_tiled_ ? (uint32_t)tiled_.waves * 64 : (uint32_t)kBlockThreads;
-    out->receptor_chunks = (uint32_t)(use_packed_ ? packed_.n_groups : use_tiled_ ? tiled_.n_groups : pair_.n_chunks);
-    out->lds_bytes = (uint32_t)(use_packed_ ? packed_kernel_lds_bytes(packed_.cells_per_unit) : use_tiled_ ? tiled_kernel_lds_bytes(tiled_) : pair_kernel_lds_bytes(pair_));
+    out->pair_kernel_name = use_bm_ ? "dfire_bm_pairs" : use_packed_ ? "dfire_packed_pairs" : use_tiled_ ? "dfire_tiled_pairs" : pair_kernel_name(method_);
+    out->block_threads = use_bm_ ? (uint32_t)kBmWaves * 64 : use_packed_ ? (uint32_t)kPackedWaves * 64 : use_tiled_ ? (uint32_t)tiled_.waves * 64 : (uint32_t)kBlockThreads;
+    out->receptor_chunks = (uint32_t)(use_bm_ ? 1 : use_packed_ ? packed_.n_groups : use_tiled_ ? tiled_.n_groups : pair_.n_chunks);
+    out->lds_bytes = (uint32_t)(use_bm_ ? bm_pairs_lds_bytes() : use_packed_ ? packed_kernel_lds_bytes(packed_.cells_per_unit) : use_tiled_ ? tiled_kernel_lds_bytes(tiled_) : pair_kernel_lds_bytes(pair_));
     out->pair_tests_per_pose = (uint64_t)pair_.rec.n * (uint64_t)pair_.lig.n;
     // DFIRE 26 B/atom (3 f64 + u16 type), DNA 48 B/atom (6 f64), + 240 B/atom
     // per ANM-deformed molecule (10 modes x 24 B), + 56 B pose in + 8 B energy out.

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "host/error.hpp"
+#include "kernels/dfire_bm.hpp"
 #include "kernels/dfire_packed.hpp"
 #include "kernels/dfire_tiled.hpp"
 #include "kernels/pose_energy.hpp"
@@ -64,6 +65,7 @@ struct DfireBinning {
 DfireBinning build_dfire_binning();                  // throws if the self-check fails
 double dfire_interface_d2();                         // largest d2 with sqrt(d2)*2-1 <= 3.9
 std::vector<uint32_t> build_packed_lut(int cells_per_unit, double eps, uint32_t zero_bins = 0);  // kPackedLutCells * cells_per_unit words
+std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins = 0);  // kBmLutBytes codes of the block-major kernel (kernels/dfire_bm.hpp)
 
 class Scorer {
    public:
@@ -111,6 +113,10 @@ class Scorer {
     void reserve_workspace(size_t n_poses, bool counts);
     void build_tiled(const ld_scorer_desc &desc);
     void build_packed(const ld_scorer_desc &desc);  // after build_tiled: shares its table, ligand and tile order
+    void build_bm(const ld_scorer_desc &desc);      // after build_packed: the block-major path for rigid molecules
+    void run_bm(size_t n, const double *d_poses, size_t stride, const uint8_t *d_active, bool counts, const uint32_t *d_list,
+                const uint32_t *d_count);
+    void frame_of_receptor(const ld_molecule &rec, double centre[3], double *half) const;
     struct TiledSoA {  // a molecule in tile order, SoA, padded to whole tiles
         int n_real = 0, n_tiles = 0;
         const double *x = nullptr, *y = nullptr, *z = nullptr;
@@ -118,6 +124,8 @@ class Scorer {
         const int32_t *slot = nullptr;
         int num_anm = 0;
         const double *modes = nullptr;
+        std::vector<double> hx, hy, hz;   // host copies, tile order (padding included)
+        std::vector<uint32_t> htype;      // DFIRE type per slot of the tile order, 0xffffffff = padding
     };
     void upload_tiled_molecule(const ld_molecule &m, bool is_receptor, TiledSoA &out);
     PrepareReceptorLaunch prepare_launch(const double *poses, size_t stride, const uint8_t *active, size_t n) const;
@@ -139,6 +147,12 @@ class Scorer {
     const uint32_t *packed_lut_full_ = nullptr;  // the LUT without elided zero bins (counting launches)
     uint32_t packed_zero_bins_ = 0;
     DeviceBuffer ws_rec_pairs_, ws_exact_;
+    bool use_bm_ = false;      // DFIRE without ANM: the block-major path (kernels/dfire_bm.hpp) evaluates every batch
+    BmModel bm_;
+    TiledSoA tiled_lig_soa_;
+    size_t bm_chunk_ = 0;      // poses per block-major pass (bounds the entry workspace)
+    DeviceBuffer ws_bm_rt_, ws_bm_tp_count_, ws_bm_ent_pose_, ws_bm_ent_mask_, ws_bm_ent_partial_, ws_bm_ent_count_, ws_bm_vis_count_,
+        ws_bm_vis_entry_, ws_bm_tile_tested_, ws_bm_exact_fix_, ws_bm_exact_count_, ws_bm_exact_pairs_;
     TiledSoA tiled_rec_soa_;          // receptor in tile order (input of dfire_prepare_receptor)
     bool rec_anm_per_pose_ = false;   // receptor ANM: one receptor image per pose per launch
     DeviceBuffer ws_rec_atoms_, ws_rec_sub_, ws_rec_tile_;

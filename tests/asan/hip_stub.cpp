@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "kernels/dfire_bm.hpp"
 #include "kernels/dfire_packed.hpp"
 #include "kernels/dfire_tiled.hpp"
 #include "kernels/gso_step.hpp"
@@ -76,6 +77,30 @@ hipError_t launch_prepare_receptor(const PrepareReceptorLaunch &p, hipStream_t) 
 size_t packed_kernel_lds_bytes(int) { return 0; }
 hipError_t launch_dfire_packed(const PackedLaunch &t, hipStream_t) {
     if (t.n_poses && t.partial) t.partial[2 * (t.n_poses * (size_t)t.n_groups - 1) + 1] = 0.0;
+    return hipSuccess;
+}
+size_t bm_pairs_lds_bytes() { return 0; }
+hipError_t launch_bm_pose(const BmLaunch &t, hipStream_t) {
+    if (t.n_poses && t.rt) t.rt[12 * (t.first + t.n_poses) - 1] = 0.f;   // last slot of the affine maps
+    return hipSuccess;
+}
+hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t) {
+    const size_t tile_pairs = (size_t)t.m.lig.n_tiles * t.m.rec_n_tiles;
+    if (t.n_poses) {
+        t.ent_pose[tile_pairs * t.cap - 1] = 0;
+        t.ent_mask[tile_pairs * t.cap - 1] = 0;
+        t.vis_entry[(t.first + t.n_poses) * tile_pairs - 1] = 0;
+        t.vis_count[(t.first + t.n_poses) * (size_t)t.m.lig.n_tiles - 1] = 0;
+    }
+    return hipSuccess;
+}
+hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t) {
+    const size_t tile_pairs = (size_t)t.m.lig.n_tiles * t.m.rec_n_tiles;
+    if (t.n_poses) t.ent_partial[tile_pairs * 8 * t.cap - 1] = 0.0;
+    return hipSuccess;
+}
+hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t) {
+    if (t.n_poses) t.partial[2 * (t.first + t.n_poses) - 1] = 0.0;
     return hipSuccess;
 }
 hipError_t launch_packed_prepare(const PackedPrepareLaunch &p, hipStream_t) {

@@ -16,7 +16,7 @@ from conftest import case_kwargs, case_positions  # noqa: E402
 pkg, orc = ge.package(), ge.oracle()
 pkg.init(0)
 table = pkg.synth.dcparams()
-VARIANTS = [("packed2", {}), ("packed1", {"LIGHTDOCK_PACKED_CELLS": "1"}), ("eps50", {"LIGHTDOCK_PACKED_EPS_SCALE": "50"}),
+VARIANTS = [("default", {}), ("packed", {"LIGHTDOCK_DFIRE_KERNEL": "packed"}), ("packed2", {"LIGHTDOCK_DFIRE_KERNEL": "packed", "LIGHTDOCK_PACKED_CELLS": "2"}), ("eps50", {"LIGHTDOCK_PACKED_EPS_SCALE": "50"}),
             ("tiled", {"LIGHTDOCK_DFIRE_KERNEL": "tiled"}), ("allpairs", {"LIGHTDOCK_DFIRE_KERNEL": "allpairs"})]
 for name in sys.argv[1:] or ["1ppe", "1k4c", "2uuy"]:
     method, rec, lig, kw = case_kwargs(name, orc, table)
