@@ -194,6 +194,10 @@ __global__ __launch_bounds__(64) void dfire_bm_cull(const BmLaunch launch_argume
             const uint32_t idx = atomicAdd(&T->tp_count[tp], 1u);
             T->ent_pose[tp * T->cap + idx] = (uint32_t)pose;
             T->ent_mask[tp * T->cap + idx] = s_mask[v];
+            float4 *ap = reinterpret_cast<float4 *>(T->ent_rt) + (tp * T->cap + idx) * 3;   // what a pair batch poses the entry with
+            ap[0] = float4{A.r00, A.r01, A.r02, A.tx};
+            ap[1] = float4{A.r10, A.r11, A.r12, A.ty};
+            ap[2] = float4{A.r20, A.r21, A.r22, A.tz};
             T->vis_entry[slot * (size_t)n_rt + v] = RT << 24 | idx;
         }
     }
@@ -204,14 +208,62 @@ __global__ __launch_bounds__(64) void dfire_bm_cull(const BmLaunch launch_argume
 }
 
 // ---------------------------------------------------------------------------------------------
-// dfire_bm_pairs: workgroup = (tile pair, ligand subtile a, part of the pair's entries); 8 waves
+// dfire_bm_plan: every tile pair's entries cut into parts of kBmPartEntries; a JOB = (tile pair, part, ligand subtile a)
+// is what one wave of dfire_bm_pairs walks.
 // ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void dfire_bm_plan(const BmLaunch launch_arguments) {
+    // One workgroup.  Jobs are listed longest first (by entries, in classes of 64): the persistent waves of
+    // dfire_bm_pairs draw them in that order, so the launch ends on its shortest jobs.
+    BmArgs *T = LD_BM_ARGS;
+    __shared__ uint32_t s_class[18];   // [c]: parts of c * 64 - 63 .. c * 64 entries; then cursors
+    const int tid = threadIdx.x;
+    const uint32_t n_tp = (uint32_t)(T->m.lig.n_tiles * T->m.rec_n_tiles);
+    if (tid < 18) s_class[tid] = 0;
+    __syncthreads();
+    for (uint32_t tp = tid; tp < n_tp; tp += 1024) {
+        const uint32_t n = T->tp_count[tp];
+        if (n == 0) continue;
+        const uint32_t full = n / kBmPartEntries, rest = n % kBmPartEntries;
+        if (full) atomicAdd(&s_class[kBmPartEntries / 64], full);
+        if (rest) atomicAdd(&s_class[(rest + 63) / 64], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t at = 0;
+        for (int c = kBmPartEntries / 64; c >= 1; c--) {
+            const uint32_t k = s_class[c];
+            s_class[c] = at;
+            at += k;
+        }
+        *T->job_count = at;
+    }
+    __syncthreads();
+    for (uint32_t tp = tid; tp < n_tp; tp += 1024) {
+        const uint32_t n = T->tp_count[tp];
+        if (n == 0) continue;
+        const uint32_t full = n / kBmPartEntries, rest = n % kBmPartEntries;
+        if (full) {
+            const uint32_t at = atomicAdd(&s_class[kBmPartEntries / 64], full);
+            for (uint32_t k = 0; k < full; k++) T->jobs[at + k] = tp << 8 | k;   // parts <= 255: cap <= 255 * kBmPartEntries (scorer.cpp)
+        }
+        if (rest) T->jobs[atomicAdd(&s_class[(rest + 63) / 64], 1u)] = tp << 8 | full;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dfire_bm_pairs: persistent workgroups (one per CU) of 8 independent waves; a wave draws jobs
+// (tile pair, part of its entries, ligand subtile a) and walks the job's 8 blocks (a, b), each with its 64 table
+// rows staged in the wave's own slice of LDS.  The waves share the cell LUT and nothing else: no barrier after set-up.
+// ---------------------------------------------------------------------------------------------
+struct BmWaveShared {
+    unsigned char cube[kBmCubeBytes];
+    unsigned char row_bits[kBmPartEntries];        // per entry of the job: which of the 8 blocks (a, .) it holds
+    unsigned short items[kBmPartEntries + 64];     // the entries that hold the current block (| 0x8000: its first block of the row)
+    uint32_t queue[kBmQueue];                      // pairs for the exact path
+};
 struct BmShared {
-    unsigned char cube[2][kBmCubeBytes];
-    unsigned char lut[kBmLutBytes];
-    unsigned char row_bits[kBmWaves][kBmPartEntries / kBmWaves];  // per entry of a wave's range: which of the 8 blocks (a, .) it holds
-    uint32_t pend[kBmWaves][128];                                   // ring: entries waiting for the next batch
-    uint32_t queue[kBmWaves][kBmQueue];                             // pairs for the exact path
+    unsigned char lut[2 * kBmLutBytes];   // [0]: blocks with a tracked atom (cells below the interface distance flagged), [1]: without
+    BmWaveShared w[kBmWaves];
 };
 
 // what a wave needs to evaluate queued pairs exactly
@@ -219,16 +271,16 @@ struct BmWaveCtx {
     size_t tp;       // tile pair
     int ls;          // ligand subtile (global)
     int RT;          // receptor tile
-    size_t my_lo;    // first entry of this wave's range
+    size_t lo;       // first entry of the job
 };
 
-// Queue item: entry (local to the wave's range) | (i * 8 + j) << 9 | b << 15
+// Queue item: entry (local to the job) | (i * 8 + j) << 10 | b << 16
 template <bool COUNT>
 __device__ __noinline__ void bm_drain(BmArgs *T, const BmWaveCtx &W, const uint32_t *queue, uint32_t queued, int lane) {
     for (uint32_t k = (uint32_t)lane; k < queued; k += 64) {
         const uint32_t item = queue[k];
-        const size_t e = W.my_lo + (item & 511u);
-        const int i = (int)((item >> 12) & 7u), j = (int)((item >> 9) & 7u), b = (int)(item >> 15);
+        const size_t e = W.lo + (item & 1023u);
+        const int i = (int)((item >> 13) & 7u), j = (int)((item >> 10) & 7u), b = (int)(item >> 16);
         const int la = W.ls * 8 + i, ra = W.RT * 64 + b * 8 + j;
         if (la >= T->m.lig.n_real || ra >= T->m.rec_n_real) continue;
         const size_t pose = T->ent_pose[W.tp * T->cap + e];
@@ -256,7 +308,7 @@ __device__ __noinline__ void bm_exact_batch(BmArgs *T, const BmWaveCtx &W, int b
     acc = 0.0;
     cnt = 0;
     for (int k = 0; k < count; k++) {
-        const size_t e = W.my_lo + (size_t)__builtin_amdgcn_readlane((int)el, k);
+        const size_t e = W.lo + (size_t)__builtin_amdgcn_readlane((int)el, k);
         const size_t pose = T->ent_pose[W.tp * T->cap + e];
         double v = 0.0;
         uint32_t c = 0;
@@ -279,174 +331,240 @@ __device__ __noinline__ void bm_exact_batch(BmArgs *T, const BmWaveCtx &W, int b
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBmWaves * 64, 4) void dfire_bm_pairs(const BmLaunch launch_arguments) {
+__global__ __launch_bounds__(kBmWaves * 64, 2) void dfire_bm_pairs(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
     __shared__ __attribute__((aligned(16))) BmShared S;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_rt = T->m.rec_n_tiles;
-    const unsigned parts = (unsigned)((T->cap + kBmPartEntries - 1) / kBmPartEntries);
-    const unsigned job = blockIdx.x / parts, part = blockIdx.x % parts;
-    const size_t tp = job >> 3;
-    const int a = (int)(job & 7u);
-    const uint32_t n = T->tp_count[tp];
-    const uint32_t lo = part * (uint32_t)kBmPartEntries;
-    if (lo >= n) return;
-    const uint32_t hi = n < lo + (uint32_t)kBmPartEntries ? n : lo + (uint32_t)kBmPartEntries;
-    const int lt = (int)(tp / (unsigned)n_rt), RT = (int)(tp % (unsigned)n_rt);
-    const int ls = lt * 8 + a;
-
-    // ---- set-up: LUT, zero slots behind the cubes, this wave's entries
     {
         const uint8_t *lut = COUNT ? T->m.lut_full : T->m.lut;
-        for (int i = tid; i < kBmLutBytes / 16; i += kBmWaves * 64) reinterpret_cast<uint4 *>(S.lut)[i] = reinterpret_cast<const uint4 *>(lut)[i];
-        if (tid < 8) reinterpret_cast<uint32_t *>(S.cube[tid >> 2] + 64 * kBmRowBytes)[tid & 3] = 0u;
+        for (int i = tid; i < 2 * kBmLutBytes / 16; i += kBmWaves * 64) reinterpret_cast<uint4 *>(S.lut)[i] = reinterpret_cast<const uint4 *>(lut)[i];
     }
-    const uint32_t per_wave = ((hi - lo + kBmWaves * 64 - 1) / (kBmWaves * 64)) * 64;   // <= 512
-    const uint32_t my_lo = lo + (uint32_t)wave * per_wave;
-    const uint32_t my_hi = my_lo + per_wave < hi ? my_lo + per_wave : hi;
-    const int n_chunks = my_lo < my_hi ? (int)((my_hi - my_lo + 63) / 64) : 0;
-    for (int k = 0; k < n_chunks; k++) {
-        const uint32_t e = my_lo + (uint32_t)k * 64 + lane;
-        const unsigned long long m = e < my_hi ? T->ent_mask[tp * T->cap + e] : 0ull;
-        S.row_bits[wave][k * 64 + lane] = (unsigned char)(m >> (8 * a));
-    }
-    BmWaveCtx W{tp, ls, RT, my_lo};
+    BmWaveShared &WS = S.w[wave];
+    if (lane < 4) reinterpret_cast<uint32_t *>(WS.cube + 64 * kBmRowBytes)[lane] = 0u;   // the zero slot behind the last row
+    __syncthreads();
+    const unsigned char *cube = WS.cube;
+    const uint32_t n_jobs = *T->job_count * 8u;
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dbg_jobs = 0, dbg_batches = 0, dbg_t_batch = 0, dbg_t_drain = 0, dbg_t_scan = 0, dbg_drains = 0;
 
-    // the ligand subtile's local coordinates (uniform)
-    float Lx[8], Ly[8], Lz[8];
-    bool Lreal[8];
+    for (;;) {
+        uint32_t job = 0;
+        if (lane == 0) job = atomicAdd(T->job_next, 1u);
+        job = (uint32_t)__builtin_amdgcn_readfirstlane((int)job);
+        if (job >= n_jobs) break;
+        const uint32_t jd = T->jobs[job >> 3];
+        const int a = (int)(job & 7u);
+        const size_t tp = jd >> 8;
+        const uint32_t lo = (jd & 255u) * (uint32_t)kBmPartEntries;
+        const uint32_t n = T->tp_count[tp];
+        const uint32_t hi = n < lo + (uint32_t)kBmPartEntries ? n : lo + (uint32_t)kBmPartEntries;
+        const int n_chunks = (int)((hi - lo + 63) / 64);
+        const int lt = (int)(tp / (unsigned)n_rt), RT = (int)(tp % (unsigned)n_rt);
+        const int ls = lt * 8 + a;
+        const BmWaveCtx W{tp, ls, RT, lo};
+        const bool lig_tracked = T->m.lig_sub_tracked[ls] != 0;
+
+        uint32_t any_bits = 0;
+        {   // the job's block masks: all loads in flight at once
+            static_assert(kBmPartEntries == 1024, "16 chunks of 64 entries");
+            unsigned long long m[16];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const float4 v = reinterpret_cast<const float4 *>(T->m.lig_local)[ls * 8 + i];
-        Lx[i] = v.x; Ly[i] = v.y; Lz[i] = v.z;
-        Lreal[i] = v.w != 0.f;
-    }
-
-    // ---- table rows of a block -> LDS: 704 pieces of 16 bytes, one LDS-DMA instruction per KiB
-    const int piece0 = wave * 64 + lane, piece1 = (wave + 8) * 64 + lane;   // wave w copies KiB w and, if w < 3, KiB w + 8
-    const int row0 = piece0 / 11, row1 = piece1 / 11;
-    const uint32_t src0 = T->m.lig_rowbase[ls * 8 + (row0 >> 3)] + (uint32_t)(piece0 % 11) * 16u;
-    const uint32_t src1 = wave < 3 ? T->m.lig_rowbase[ls * 8 + (row1 >> 3)] + (uint32_t)(piece1 % 11) * 16u : 0u;
-    auto stage_cube = [&](int b) {
-        const unsigned char *rows = reinterpret_cast<const unsigned char *>(T->m.rows);
-        const uint32_t *roff = T->m.rec_rowoff + (size_t)RT * 64 + b * 8;
-        unsigned char *dst = S.cube[b & 1];
-        __builtin_amdgcn_global_load_lds((const global_u32 *)(rows + src0 + roff[row0 & 7]), (lds_u32 *)(dst + wave * 1024), 16, 0, 0);
-        if (wave < 3)
-            __builtin_amdgcn_global_load_lds((const global_u32 *)(rows + src1 + roff[row1 & 7]), (lds_u32 *)(dst + (wave + 8) * 1024), 16, 0, 0);
-    };
-    stage_cube(0);
-
-    uint32_t queued = 0;   // wave-uniform
-
-    auto run_block = [&](auto buf_tag, int b) {
-        constexpr int BUF = decltype(buf_tag)::value;
-        const unsigned char *cube = S.cube[BUF];
-        // receptor subtile b of the tile: 4 pair records, wave-uniform
-        const PackedRecPair *rp = T->m.rec_pairs + (size_t)RT * 32 + b * 4;
-        v2f Rx[4], Ry[4], Rz[4];
+            for (int k = 0; k < 16; k++) {
+                const uint32_t e = lo + (uint32_t)k * 64 + lane;
+                m[k] = e < hi ? T->ent_mask[tp * T->cap + e] : 0ull;
+            }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            Rx[q] = v2f{rp[q].x0, rp[q].x1};
-            Ry[q] = v2f{rp[q].y0, rp[q].y1};
-            Rz[q] = v2f{rp[q].z0, rp[q].z1};
+            for (int k = 0; k < 16; k++) {
+                const uint32_t bits = (uint32_t)(m[k] >> (8 * a)) & 0xffu;
+                if (k < n_chunks) WS.row_bits[k * 64 + lane] = (unsigned char)bits;
+                any_bits |= bits;
+            }
         }
-        uint32_t pend_n = 0, pend_head = 0;
-        for (int k = 0; k <= n_chunks; k++) {
-            if (k < n_chunks) {
-                const uint32_t bits = S.row_bits[wave][k * 64 + lane];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) any_bits |= (uint32_t)__shfl_xor((int)any_bits, off, 64);
+        any_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)any_bits);
+        if (any_bits == 0) continue;
+        dbg_jobs++;
+
+        // the ligand subtile's local coordinates (uniform)
+        float Lx[8], Ly[8], Lz[8];
+        bool Lreal[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float4 v = reinterpret_cast<const float4 *>(T->m.lig_local)[ls * 8 + i];
+            Lx[i] = v.x; Ly[i] = v.y; Lz[i] = v.z;
+            Lreal[i] = v.w != 0.f;
+        }
+        // table rows of a block -> LDS: 704 pieces of 16 bytes, 11 LDS-DMA instructions of 1 KiB
+        uint32_t src_lig[11];
+#pragma unroll
+        for (int t = 0; t < 11; t++) {
+            const int piece = t * 64 + lane, row = piece / 11;
+            src_lig[t] = T->m.lig_rowbase[ls * 8 + (row >> 3)] + (uint32_t)(piece % 11) * 16u;
+        }
+        const size_t row_base = (tp * 8 + (size_t)a) * T->cap + lo;
+        const size_t ent_base = tp * T->cap + lo;
+        uint32_t queued = 0;   // wave-uniform
+
+        for (int b = 0; b < 8; b++) {
+            if (!((any_bits >> b) & 1u)) continue;
+            {   // stage the block's rows; they land while the entries are scanned
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous block's reads are done
+                const unsigned char *rows = reinterpret_cast<const unsigned char *>(T->m.rows);
+                const uint32_t my_roff = T->m.rec_rowoff[(size_t)RT * 64 + b * 8 + (lane & 7)];   // lane j (mod 8): receptor atom j's column
+#pragma unroll
+                for (int t = 0; t < 11; t++) {
+                    const int row = (t * 64 + lane) / 11;
+                    const uint32_t roff = (uint32_t)__shfl((int)my_roff, row & 7, 64);
+                    __builtin_amdgcn_global_load_lds((const global_u32 *)(rows + src_lig[t] + roff), (lds_u32 *)(WS.cube + t * 1024), 16, 0, 0);
+                }
+            }
+            // which LUT: the offset rides in the seed of the distance sum (exact: integers far below 2^24)
+            const float lut_base = lig_tracked || T->m.rec_sub_tracked[RT * 8 + b] != 0 ? 0.f : (float)kBmLutBytes;
+            const float seed = 0.5f + lut_base, cell_max = kBmCellMax + lut_base;
+            // ---- the job's entries that hold block (a, b), in entry order
+            uint32_t n_items = 0;
+            for (int k = 0; k < n_chunks; k++) {
+                const uint32_t bits = WS.row_bits[k * 64 + lane];
                 const bool act = (bits >> b) & 1u;
                 const unsigned long long m = __ballot(act);
                 if (act) {
-                    const uint32_t at = pend_head + pend_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    S.pend[wave][at & 127u] = (uint32_t)(k * 64 + lane) | bits << 16;
+                    const uint32_t at = n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    const bool first = (bits & ((1u << b) - 1u)) == 0u;   // the entry's first block in this row: nothing to add to yet
+                    WS.items[at] = (unsigned short)((uint32_t)(k * 64 + lane) | (first ? 0x8000u : 0u));
                 }
-                pend_n += (uint32_t)__popcll(m);
+                n_items += (uint32_t)__popcll(m);
             }
-            if (!(pend_n >= 64u || (k == n_chunks && pend_n > 0u))) continue;
-            // ---- one batch: lane = entry
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const int count = pend_n >= 64u ? 64 : (int)pend_n;
-            const bool valid = lane < count;
-            const uint32_t item = S.pend[wave][(pend_head + (valid ? lane : 0)) & 127u];
-            pend_head += (uint32_t)count;
-            pend_n -= (uint32_t)count;
-            const uint32_t el = item & 0xffffu, bits = item >> 16;
-            const size_t e = (size_t)my_lo + el;
-            const size_t pose = T->ent_pose[tp * T->cap + e];
-            const Affine A = bm_load_affine(T->rt, pose);
-            const size_t pslot = (tp * 8 + (size_t)a) * T->cap + e;
-            const bool first = (int)__builtin_ctz(bits) == b;   // the entry's first block in this row: nothing to add to yet
-            double prev = 0.0;
-            uint32_t prev_cnt = 0;
-            if (!first) {
-                prev = T->ent_partial[pslot];
-                if (COUNT) prev_cnt = T->ent_count[pslot];
-            }
-            float lx[8], ly[8], lz[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) bm_apply(A, Lx[i], Ly[i], Lz[i], lx[i], ly[i], lz[i]);
-            double acc = 0.0;
-            uint32_t cnt = 0;
-            const uint32_t queued_before = queued;
+            // receptor subtile b of the tile: 4 pair records, wave-uniform
+            const PackedRecPair *rp = T->m.rec_pairs + (size_t)RT * 32 + b * 4;
+            v2f Rx[4], Ry[4], Rz[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
+                Rx[q] = v2f{rp[q].x0, rp[q].x1};
+                Ry[q] = v2f{rp[q].y0, rp[q].y1};
+                Rz[q] = v2f{rp[q].z0, rp[q].z1};
+            }
+            // what a lane of a batch needs from memory, loaded one batch ahead
+            struct BatchLoads {
+                float4 a0, a1, a2;   // the entry's affine map
+                double prev;         // the entry's partial of this row so far
+                uint32_t prev_cnt;
+                uint32_t item;
+            };
+            auto issue_loads = [&](uint32_t first_item) {
+                BatchLoads L;
+                const uint32_t at = first_item + (uint32_t)lane;
+                L.item = WS.items[at < n_items ? at : first_item];
+                const uint32_t el = L.item & 0x7fffu;
+                const float4 *ap = reinterpret_cast<const float4 *>(T->ent_rt) + (ent_base + el) * 3;
+                L.a0 = ap[0];
+                L.a1 = ap[1];
+                L.a2 = ap[2];
+                L.prev = 0.0;
+                L.prev_cnt = 0;
+                if (!(L.item & 0x8000u)) {
+                    L.prev = T->ent_partial[row_base + el];
+                    if (COUNT) L.prev_cnt = T->ent_count[row_base + el];
+                }
+                return L;
+            };
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the item list as every lane wrote it
+            BatchLoads next = issue_loads(0);
+            for (uint32_t done = 0; done < n_items; done += 64) {
+                const BatchLoads cur = next;
+                dbg_batches++;
+                const unsigned long long dbg_tb = T->debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this batch's loads (and, the first time, the block's rows) are in
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (done + 64 < n_items) next = issue_loads(done + 64);
+                const int count = n_items - done >= 64u ? 64 : (int)(n_items - done);
+                const bool valid = lane < count;
+                const uint32_t el = cur.item & 0x7fffu;
+                const Affine A{cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w, cur.a2.x, cur.a2.y, cur.a2.z, cur.a2.w};
+                float lx[8], ly[8], lz[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const v2f dx = Rx[q] - v2f{lx[i], lx[i]}, dy = Ry[q] - v2f{ly[i], ly[i]}, dz = Rz[q] - v2f{lz[i], lz[i]};
-                    v2f D = __builtin_elementwise_fma(dz, dz, v2f{0.5f, 0.5f});
-                    D = __builtin_elementwise_fma(dy, dy, D);
-                    D = __builtin_elementwise_fma(dx, dx, D);
-                    const uint32_t c0 = bm_cvt_u32(fminf(D.x, kBmCellMax)), c1 = bm_cvt_u32(fminf(D.y, kBmCellMax));
-                    const uint32_t w0 = S.lut[c0], w1 = S.lut[c1];
-                    acc += *reinterpret_cast<const double *>(cube + (i * 8 + 2 * q) * kBmRowBytes + w0);
-                    acc += *reinterpret_cast<const double *>(cube + (i * 8 + 2 * q + 1) * kBmRowBytes + w1);
-                    asm volatile("" : "+v"(acc));   // add here, not 64 values later (the scheduler would park them all in registers)
-                    if (COUNT && Lreal[i]) cnt += (w0 != 0u && w0 < kBmFlagged ? 1u : 0u) + (w1 != 0u && w1 < kBmFlagged ? 1u : 0u);
-                    const uint32_t wm = w0 > w1 ? w0 : w1;
+                for (int i = 0; i < 8; i++) bm_apply(A, Lx[i], Ly[i], Lz[i], lx[i], ly[i], lz[i]);
+                double acc = 0.0;
+                uint32_t cnt = 0;
+                const uint32_t queued_before = queued;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    // a group of 8 steps: all cells, all codes, all table values, then the adds in order; one test for flagged cells
+                    uint32_t w[16];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const v2f dx = Rx[q] - v2f{lx[i], lx[i]}, dy = Ry[q] - v2f{ly[i], ly[i]}, dz = Rz[q] - v2f{lz[i], lz[i]};
+                        v2f D = __builtin_elementwise_fma(dz, dz, v2f{seed, seed});
+                        D = __builtin_elementwise_fma(dy, dy, D);
+                        D = __builtin_elementwise_fma(dx, dx, D);
+                        const uint32_t c0 = bm_cvt_u32(fminf(D.x, cell_max)), c1 = bm_cvt_u32(fminf(D.y, cell_max));
+                        w[2 * i] = S.lut[c0];
+                        w[2 * i + 1] = S.lut[c1];
+                    }
+                    uint32_t wm = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        asm volatile("" : "+v"(w[2 * i]), "+v"(w[2 * i + 1]));   // 32-bit values from here on (no 16-bit detours on the way to the address)
+                        acc += *reinterpret_cast<const double *>(cube + (i * 8 + 2 * q) * kBmRowBytes + w[2 * i]);
+                        acc += *reinterpret_cast<const double *>(cube + (i * 8 + 2 * q + 1) * kBmRowBytes + w[2 * i + 1]);
+                        if (COUNT && Lreal[i])
+                            cnt += (w[2 * i] != 0u && w[2 * i] < kBmFlagged ? 1u : 0u) + (w[2 * i + 1] != 0u && w[2 * i + 1] < kBmFlagged ? 1u : 0u);
+                        const uint32_t m2 = w[2 * i] > w[2 * i + 1] ? w[2 * i] : w[2 * i + 1];
+                        wm = wm > m2 ? wm : m2;
+                    }
+                    asm volatile("" : "+v"(acc));   // the group's adds end here (the scheduler would park table values in registers)
                     if (__builtin_expect(__ballot(wm >= kBmFlagged) != 0ull, 0)) {
-                        // (rare: keep the compiler from preparing any of this outside the branch for all 32 steps)
+                        // (rare: keep the compiler from preparing any of this outside the branch)
                         uint32_t el_here = el;
                         asm volatile("" : "+v"(el_here));
-                        const bool f0 = valid && w0 >= kBmFlagged, f1 = valid && w1 >= kBmFlagged;
-                        const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
-                        const uint32_t n0 = (uint32_t)__popcll(m0);
-                        const uint32_t i0 = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
-                        const uint32_t i1 = queued + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-                        const uint32_t qi = el_here | (uint32_t)(i * 8 + 2 * q) << 9 | (uint32_t)b << 15;
-                        if (f0 && i0 < (uint32_t)kBmQueue) S.queue[wave][i0] = qi;
-                        if (f1 && i1 < (uint32_t)kBmQueue) S.queue[wave][i1] = qi + (1u << 9);
-                        queued += n0 + (uint32_t)__popcll(m1);
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const bool f = valid && w[k] >= kBmFlagged;
+                            const unsigned long long m = __ballot(f);
+                            if (m == 0ull) continue;
+                            const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            if (f && at < (uint32_t)kBmQueue) WS.queue[at] = el_here | (uint32_t)((k >> 1) * 8 + 2 * q + (k & 1)) << 10 | (uint32_t)b << 16;
+                            queued += (uint32_t)__popcll(m);
+                        }
                     }
                 }
-            }
-            if (__builtin_expect(queued > (uint32_t)kBmQueue, 0)) {
-                queued = queued_before;   // forget what this batch queued: all of it again in f64
-                bm_exact_batch<COUNT>(T, W, b, el, count, lane, acc, cnt);
-            }
-            if (valid) {
-                T->ent_partial[pslot] = prev + acc;
-                if (COUNT) T->ent_count[pslot] = prev_cnt + cnt;
-            }
-            if (queued > (uint32_t)kBmQueue / 2) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                bm_drain<COUNT>(T, W, S.queue[wave], queued, lane);
-                queued = 0;
+                if (__builtin_expect(queued > (uint32_t)kBmQueue, 0)) {
+                    queued = queued_before;   // forget what this batch queued: all of it again in f64
+                    bm_exact_batch<COUNT>(T, W, b, el, count, lane, acc, cnt);
+                }
+                if (valid) {
+                    T->ent_partial[row_base + el] = cur.prev + acc;
+                    if (COUNT) T->ent_count[row_base + el] = cur.prev_cnt + cnt;
+                }
+                if (T->debug) dbg_t_batch += __builtin_amdgcn_s_memrealtime() - dbg_tb;
+                if (queued > (uint32_t)kBmQueue / 2) {
+                    const unsigned long long td = T->debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    bm_drain<COUNT>(T, W, WS.queue, queued, lane);
+                    queued = 0;
+                    if (T->debug) { dbg_t_drain += __builtin_amdgcn_s_memrealtime() - td; dbg_drains++; }
+                }
             }
         }
-    };
-
-    for (int b = 0; b < 8; b++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of cube b has landed (and its stores are out)
-        __syncthreads();                                   // everybody's has; nobody reads cube b - 1 any more
-        if (b + 1 < 8) stage_cube(b + 1);
-        if (b & 1) run_block(std::integral_constant<int, 1>{}, b);
-        else run_block(std::integral_constant<int, 0>{}, b);
+        if (queued) {
+            const unsigned long long td = T->debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            bm_drain<COUNT>(T, W, WS.queue, queued, lane);
+            if (T->debug) { dbg_t_drain += __builtin_amdgcn_s_memrealtime() - td; dbg_drains++; }
+        }
     }
-    if (queued) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        bm_drain<COUNT>(T, W, S.queue[wave], queued, lane);
+    if (T->debug != nullptr && lane == 0) {
+        unsigned long long *d = T->debug + ((size_t)blockIdx.x * kBmWaves + wave) * 8;
+        d[0] = dbg_t0;
+        d[1] = __builtin_amdgcn_s_memrealtime();
+        d[2] = dbg_jobs;
+        d[3] = dbg_batches;
+        d[4] = dbg_t_batch;
+        d[5] = dbg_t_drain;
+        d[6] = dbg_drains;
+        d[7] = dbg_t_scan;
     }
 }
 
@@ -518,11 +636,10 @@ hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream) {
 
 hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    const size_t parts = (t.cap + kBmPartEntries - 1) / kBmPartEntries;
-    const size_t blocks = (size_t)t.m.lig.n_tiles * t.m.rec_n_tiles * 8 * parts;
-    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
-    if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_pairs<true>), dim3((unsigned)blocks), dim3(kBmWaves * 64), 0, stream, t);
-    else hipLaunchKernelGGL((dfire_bm_pairs<false>), dim3((unsigned)blocks), dim3(kBmWaves * 64), 0, stream, t);
+    hipLaunchKernelGGL(dfire_bm_plan, dim3(1), dim3(1024), 0, stream, t);
+    const unsigned groups = t.pairs_groups > 0 ? (unsigned)t.pairs_groups : 256u;   // persistent: one workgroup per CU
+    if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_pairs<true>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
+    else hipLaunchKernelGGL((dfire_bm_pairs<false>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
     return hipGetLastError();
 }
 

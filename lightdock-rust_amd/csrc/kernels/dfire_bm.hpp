@@ -47,7 +47,7 @@ constexpr int kBmCubeBytes = 64 * kBmRowBytes + 16;  // + one zero slot behind t
 constexpr uint32_t kBmFlagged = kBmRowBytes;  // LUT code of a flagged cell: slot 0 of the NEXT row = 0.0, above every bin code
 constexpr int kBmTypes = 170;                // 169 DFIRE types + one all-zero type for padding atoms
 constexpr int kBmWaves = 8;                  // waves per dfire_bm_pairs workgroup
-constexpr int kBmPartEntries = 4096;         // entries of a tile pair one workgroup walks (512 per wave)
+constexpr int kBmPartEntries = 1024;         // entries of a tile pair in one job
 constexpr int kBmQueue = 256;                // per wave: pairs waiting for the exact path
 constexpr double kBmFixScale = 1099511627776.0;  // 2^40: fixed-point units of the exact path's sum
 
@@ -68,7 +68,9 @@ struct BmModel {
     const uint32_t *lig_rowbase = nullptr;      // [n_tiles*64]: byte offset of the atom's type block in `rows`
     // tables
     const double *rows = nullptr;               // [kBmTypes lig][kBmTypes rec][kBmRowSlots]
-    const uint8_t *lut = nullptr;               // kBmLutBytes codes
+    const uint8_t *lut = nullptr;               // 2 x kBmLutBytes codes: for blocks with / without an atom that has an interface-flag slot
+    const uint8_t *rec_sub_tracked = nullptr;   // [rec subtiles]: 1 = holds an atom with a flag slot
+    const uint8_t *lig_sub_tracked = nullptr;   // [lig subtiles]
     const uint8_t *lut_full = nullptr;          // the same without elided zero bins (counting launches)
     const double *table = nullptr;              // 2 x 2 x 4 patches (dfire_tiled.hpp): the exact path's table
     const double *bin_step = nullptr;
@@ -94,8 +96,14 @@ struct BmLaunch {
     uint32_t *tp_count = nullptr;          // [n_tile_pairs], zeroed per launch
     uint32_t *ent_pose = nullptr;          // [tile pair][cap]
     unsigned long long *ent_mask = nullptr;  // [tile pair][cap]
+    float *ent_rt = nullptr;               // [tile pair][cap][12]: the entry's pose as the f32 affine map
     double *ent_partial = nullptr;         // [tile pair][8][cap]
     uint32_t *ent_count = nullptr;         // [tile pair][8][cap] or nullptr (counting launches)
+    uint32_t *jobs = nullptr;              // [tile pairs * parts]: tile pair << 8 | part, written by dfire_bm_plan
+    uint32_t *job_count = nullptr;         // [2], zeroed per launch: jobs listed, jobs drawn (job_next = job_count + 1)
+    uint32_t *job_next = nullptr;
+    int pairs_groups = 0;                  // workgroups of dfire_bm_pairs (0: one per CU of an MI355X)
+    unsigned long long *debug = nullptr;   // diagnostics (LIGHTDOCK_BM_DEBUG): per wave of dfire_bm_pairs {start, end (100 MHz), jobs, batches}
     uint32_t *vis_count = nullptr;         // [pose][lig tiles]
     uint32_t *vis_entry = nullptr;         // [pose][lig tiles][rec tiles]: receptor tile << 24 | entry
     uint32_t *tile_tested = nullptr;       // [pose][lig tiles]: 8x8 blocks let through (diagnostics) or nullptr

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -246,6 +247,7 @@ Scorer::Scorer(const ld_scorer_desc &desc) {
     hip_check(hipGetDevice(&device_), "hipGetDevice");
     hipDeviceProp_t prop;
     hip_check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
+    n_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("LIGHTDOCK_ALLOW_ANY_ARCH"))
         throw Error(LD_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
 
@@ -342,6 +344,7 @@ void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, Tiled
     out.hy = y;
     out.hz = z;
     out.htype.assign(np, kPad);
+    out.hslot = slot;
     for (size_t i = 0; i < np; i++)
         if (order[i] != kPad) out.htype[i] = m.dfire_types[order[i]];
     out.x = arena_.upload(x);
@@ -649,14 +652,15 @@ double dfire_bm_error_bound(double ubound, double lig_extent) {
 // in the block's table rows ((bin + 1) * 8; 0 = "miss" beyond the cutoff or a bin that is zero for the whole complex);
 // any other cell -- a bin step, the interface distance or the cutoff inside, or all of it below the interface distance
 // (src/dfire.rs:339: flags to set) -- is flagged: the kernel reads 0.0 and recomputes the pair in f64.
-std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins) {
+std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins, bool sets_flags) {
     const DfireBinning b = build_dfire_binning();
     const double iface_scaled = 4.0 * dfire_interface_d2();
     std::vector<uint8_t> codes(kBmLutBytes, 0);
     for (int k = 0; k < kBmLutBytes; k++) {
         const double ilo = (k - 0.5 - eps_cells) / kBmCells, ihi = (k + 0.5 + eps_cells) / kBmCells;
         if (ilo > 900.0) continue;  // beyond the cutoff for sure
-        bool flagged = ihi >= 900.0 || ilo <= iface_scaled;
+        // (a block none of whose atoms has an interface-flag slot has no flag to set: its clashing pairs are ordinary pairs)
+        bool flagged = ihi >= 900.0 || (sets_flags && ilo <= iface_scaled);
         int base_bin = 0;
         for (int s = 1; s <= 20; s++) {
             const double at = 4.0 * b.step[s];
@@ -732,8 +736,23 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
         for (double &v : step4) v *= 4.0;
         M.bin_step = arena_.upload(step4);
     }
-    M.lut = arena_.upload(build_bm_lut(eps, packed_zero_bins_));
-    M.lut_full = packed_zero_bins_ ? arena_.upload(build_bm_lut(eps, 0)) : M.lut;  // counting launches count every pair
+    auto two_luts = [&](uint32_t zero_bins) {   // [0]: blocks with a tracked atom, [1]: blocks without
+        std::vector<uint8_t> both = build_bm_lut(eps, zero_bins, true), plain = build_bm_lut(eps, zero_bins, false);
+        both.insert(both.end(), plain.begin(), plain.end());
+        return both;
+    };
+    M.lut = arena_.upload(two_luts(packed_zero_bins_));
+    M.lut_full = packed_zero_bins_ ? arena_.upload(two_luts(0)) : M.lut;  // counting launches count every pair
+    {   // subtiles that hold an atom with an interface-flag slot (restraint atoms, membrane beads)
+        auto tracked = [](const TiledSoA &m) {
+            std::vector<uint8_t> t(m.hslot.size() / 8, 0);
+            for (size_t i = 0; i < m.hslot.size(); i++)
+                if (m.hslot[i] >= 0) t[i / 8] = 1;
+            return t;
+        };
+        M.rec_sub_tracked = arena_.upload(tracked(rec));
+        M.lig_sub_tracked = arena_.upload(tracked(lig));
+    }
 
     {   // receptor image in this frame, by the kernel that builds the packed kernel's
         const size_t pad = (size_t)rec.n_tiles * 64;
@@ -784,13 +803,14 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
                 }
         M.rows = arena_.upload(rows);
     }
-    // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x 76 bytes (108 with counts)
+    // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x 124 bytes (156 with counts)
     const size_t tile_pairs = (size_t)rec.n_tiles * lig.n_tiles;
-    size_t chunk = ((size_t)3 << 30) / (108 * tile_pairs);
+    size_t chunk = ((size_t)4 << 30) / (156 * tile_pairs);
     chunk = std::max<size_t>(kBmPartEntries, chunk / kBmPartEntries * kBmPartEntries);
+    chunk = std::min<size_t>(chunk, (size_t)255 * kBmPartEntries);   // a job names its part in 8 bits
     if (const char *e = std::getenv("LIGHTDOCK_BM_CHUNK")) {
         const long v = std::atol(e);
-        if (v >= 1) chunk = (size_t)v;
+        if (v >= 1) chunk = std::min<size_t>((size_t)v, (size_t)255 * kBmPartEntries);
     }
     bm_chunk_ = chunk;
     use_bm_ = true;
@@ -810,8 +830,13 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
     t.cap = cap;
     t.rt = static_cast<float *>(ws_bm_rt_.ptr);
     t.tp_count = static_cast<uint32_t *>(ws_bm_tp_count_.ptr);
+    t.job_count = t.tp_count + tile_pairs;
+    t.job_next = t.tp_count + tile_pairs + 1;
+    t.jobs = static_cast<uint32_t *>(ws_bm_jobs_.ptr);
+    t.pairs_groups = n_cus_;
     t.ent_pose = static_cast<uint32_t *>(ws_bm_ent_pose_.ptr);
     t.ent_mask = static_cast<unsigned long long *>(ws_bm_ent_mask_.ptr);
+    t.ent_rt = static_cast<float *>(ws_bm_ent_rt_.ptr);
     t.ent_partial = static_cast<double *>(ws_bm_ent_partial_.ptr);
     t.vis_count = static_cast<uint32_t *>(ws_bm_vis_count_.ptr);
     t.vis_entry = static_cast<uint32_t *>(ws_bm_vis_entry_.ptr);
@@ -827,14 +852,29 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         t.tested_partial = static_cast<uint32_t *>(ws_tested_.ptr);
         t.exact_partial = static_cast<uint32_t *>(ws_exact_.ptr);
     }
+    const char *dbg = std::getenv("LIGHTDOCK_BM_DEBUG");
+    if (dbg) {
+        ws_bm_debug_.reserve((size_t)n_cus_ * kBmWaves * 8 * sizeof(unsigned long long));
+        t.debug = static_cast<unsigned long long *>(ws_bm_debug_.ptr);
+    }
     for (size_t off = 0; off < n; off += cap) {  // poses are independent: passes of at most `cap` poses
         t.first = off;
         t.n_poses = std::min(cap, n - off);
-        hip_check(hipMemsetAsync(t.tp_count, 0, tile_pairs * sizeof(uint32_t), stream_), "hipMemsetAsync(tile pair counts)");
+        hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + 2) * sizeof(uint32_t), stream_), "hipMemsetAsync(tile pair counts)");
         hip_check(launch_bm_pose(t, stream_), "launch dfire_bm_pose");
         hip_check(launch_bm_cull(t, stream_), "launch dfire_bm_cull");
         hip_check(launch_bm_pairs(t, stream_), "launch dfire_bm_pairs");
         hip_check(launch_bm_gather(t, stream_), "launch dfire_bm_gather");
+    }
+    if (dbg) {   // diagnostics: wave lifetimes of the last pass, one text line per wave
+        hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        std::vector<unsigned long long> h((size_t)n_cus_ * kBmWaves * 8);
+        hip_check(hipMemcpy(h.data(), t.debug, h.size() * 8, hipMemcpyDeviceToHost), "D2H debug");
+        if (FILE *f = std::fopen(dbg, "w")) {
+            for (size_t i = 0; i < h.size(); i += 8)
+                std::fprintf(f, "%llu %llu %llu %llu %llu %llu %llu %llu\n", h[i], h[i + 1], h[i + 2], h[i + 3], h[i + 4], h[i + 5], h[i + 6], h[i + 7]);
+            std::fclose(f);
+        }
     }
 }
 
@@ -897,7 +937,7 @@ Scorer::~Scorer() {
     ws_rec_tile_.release();
     ws_rec_pairs_.release();
     ws_exact_.release();
-    for (DeviceBuffer *b : {&ws_bm_rt_, &ws_bm_tp_count_, &ws_bm_ent_pose_, &ws_bm_ent_mask_, &ws_bm_ent_partial_, &ws_bm_ent_count_, &ws_bm_vis_count_,
+    for (DeviceBuffer *b : {&ws_bm_rt_, &ws_bm_tp_count_, &ws_bm_ent_pose_, &ws_bm_jobs_, &ws_bm_ent_mask_, &ws_bm_ent_rt_, &ws_bm_ent_partial_, &ws_bm_ent_count_, &ws_bm_vis_count_,
                             &ws_bm_vis_entry_, &ws_bm_tile_tested_, &ws_bm_exact_fix_, &ws_bm_exact_count_, &ws_bm_exact_pairs_})
         b->release();
     ws_poses_.release();
@@ -907,7 +947,7 @@ Scorer::~Scorer() {
 uint64_t Scorer::workspace_generation() const {
     return ws_partial_.generation + ws_flags_.generation + ws_counts_.generation + ws_tested_.generation + ws_exact_.generation +
            ws_rec_atoms_.generation + ws_rec_sub_.generation + ws_rec_tile_.generation + ws_rec_pairs_.generation + ws_bm_rt_.generation +
-           ws_bm_tp_count_.generation + ws_bm_ent_pose_.generation + ws_bm_ent_mask_.generation + ws_bm_ent_partial_.generation +
+           ws_bm_tp_count_.generation + ws_bm_ent_pose_.generation + ws_bm_jobs_.generation + ws_bm_ent_mask_.generation + ws_bm_ent_rt_.generation + ws_bm_ent_partial_.generation +
            ws_bm_ent_count_.generation + ws_bm_vis_count_.generation + ws_bm_vis_entry_.generation + ws_bm_tile_tested_.generation +
            ws_bm_exact_fix_.generation + ws_bm_exact_count_.generation + ws_bm_exact_pairs_.generation;
 }
@@ -926,9 +966,11 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         const size_t n = n_poses, n_lt = (size_t)bm_.lig.n_tiles, n_rt = (size_t)bm_.rec_n_tiles, tile_pairs = n_lt * n_rt;
         const size_t cap = std::min(n, bm_chunk_);
         ws_bm_rt_.reserve(n * 12 * sizeof(float));
-        ws_bm_tp_count_.reserve(tile_pairs * sizeof(uint32_t));
+        ws_bm_tp_count_.reserve((tile_pairs + 2) * sizeof(uint32_t));   // + jobs listed, jobs drawn
+        ws_bm_jobs_.reserve(tile_pairs * ((cap + kBmPartEntries - 1) / kBmPartEntries) * sizeof(uint32_t));
         ws_bm_ent_pose_.reserve(tile_pairs * cap * sizeof(uint32_t));
         ws_bm_ent_mask_.reserve(tile_pairs * cap * sizeof(unsigned long long));
+        ws_bm_ent_rt_.reserve(tile_pairs * cap * 12 * sizeof(float));
         ws_bm_ent_partial_.reserve(tile_pairs * 8 * cap * sizeof(double));
         ws_bm_vis_count_.reserve(n * n_lt * sizeof(uint32_t));
         ws_bm_vis_entry_.reserve(n * tile_pairs * sizeof(uint32_t));

@@ -65,7 +65,7 @@ struct DfireBinning {
 DfireBinning build_dfire_binning();                  // throws if the self-check fails
 double dfire_interface_d2();                         // largest d2 with sqrt(d2)*2-1 <= 3.9
 std::vector<uint32_t> build_packed_lut(int cells_per_unit, double eps, uint32_t zero_bins = 0);  // kPackedLutCells * cells_per_unit words
-std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins = 0);  // kBmLutBytes codes of the block-major kernel (kernels/dfire_bm.hpp)
+std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins = 0, bool sets_flags = true);  // kBmLutBytes codes of the block-major kernel (kernels/dfire_bm.hpp)
 
 class Scorer {
    public:
@@ -126,6 +126,7 @@ class Scorer {
         const double *modes = nullptr;
         std::vector<double> hx, hy, hz;   // host copies, tile order (padding included)
         std::vector<uint32_t> htype;      // DFIRE type per slot of the tile order, 0xffffffff = padding
+        std::vector<int32_t> hslot;       // interface-flag slot or -1
     };
     void upload_tiled_molecule(const ld_molecule &m, bool is_receptor, TiledSoA &out);
     PrepareReceptorLaunch prepare_launch(const double *poses, size_t stride, const uint8_t *active, size_t n) const;
@@ -151,7 +152,8 @@ class Scorer {
     BmModel bm_;
     TiledSoA tiled_lig_soa_;
     size_t bm_chunk_ = 0;      // poses per block-major pass (bounds the entry workspace)
-    DeviceBuffer ws_bm_rt_, ws_bm_tp_count_, ws_bm_ent_pose_, ws_bm_ent_mask_, ws_bm_ent_partial_, ws_bm_ent_count_, ws_bm_vis_count_,
+    int n_cus_ = 256;
+    DeviceBuffer ws_bm_debug_, ws_bm_jobs_, ws_bm_rt_, ws_bm_tp_count_, ws_bm_ent_pose_, ws_bm_ent_mask_, ws_bm_ent_rt_, ws_bm_ent_partial_, ws_bm_ent_count_, ws_bm_vis_count_,
         ws_bm_vis_entry_, ws_bm_tile_tested_, ws_bm_exact_fix_, ws_bm_exact_count_, ws_bm_exact_pairs_;
     TiledSoA tiled_rec_soa_;          // receptor in tile order (input of dfire_prepare_receptor)
     bool rec_anm_per_pose_ = false;   // receptor ANM: one receptor image per pose per launch
