@@ -21,6 +21,8 @@ namespace {
 typedef const __attribute__((address_space(4))) BmLaunch BmArgs;
 #define LD_BM_ARGS ((BmArgs *)__builtin_amdgcn_kernarg_segment_ptr())
 
+constexpr int kBmCullWaves = 4;   // independent waves per dfire_bm_cull workgroup
+constexpr int kBmCullPoses = 1;   // poses a wave of dfire_bm_cull walks with its ligand tile
 constexpr float kBmBoxCut = 14400.0f * 1.00005f;  // (8 * 15 A)^2 in record units, padded for the rounding of the box test
 
 __device__ __forceinline__ uint32_t bm_cvt_u32(float f) {  // v_cvt_u32_f32 saturates: negative and NaN -> 0
@@ -118,93 +120,166 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
 }
 
 // ---------------------------------------------------------------------------------------------
-// dfire_bm_cull: wave = (pose, ligand tile)
+// dfire_bm_cull: wave = (ligand tile, kBmCullPoses consecutive poses of the launch).  The kernel is bound by memory
+// latency (a handful of dependent loads and one returning atomic per pose), so a wave keeps what does not depend on the
+// pose in registers -- its ligand atom, its receptor tile's box -- and the appends of one pose complete while the next
+// pose is culled.
 // ---------------------------------------------------------------------------------------------
+struct CullAppend {       // one surviving tile pair per lane, waiting for its entry number
+    uint32_t idx;         // returned by the atomic
+    uint32_t RT;
+    unsigned long long mask;
+    bool on;
+};
+
 template <bool COUNT>
-__global__ __launch_bounds__(64) void dfire_bm_cull(const BmLaunch launch_arguments) {
+__global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
-    __shared__ unsigned long long s_mask[256];
-    __shared__ uint32_t s_rt[256];
-    const int lane = threadIdx.x;
+    __shared__ unsigned long long s_mask_all[kBmCullWaves][256];
+    __shared__ uint32_t s_rt_all[kBmCullWaves][256];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    unsigned long long *s_mask = s_mask_all[wave];
+    uint32_t *s_rt = s_rt_all[wave];
     const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
-    const size_t listed = blockIdx.x / (unsigned)n_lt;
-    const int lt = (int)(blockIdx.x % (unsigned)n_lt);
-    const long long pp = bm_pose_of(T, listed);
-    if (pp < 0) return;
-    const size_t pose = (size_t)pp;
-    const size_t slot = pose * (size_t)n_lt + lt;
+    const size_t item = (size_t)blockIdx.x * kBmCullWaves + wave;   // the waves of a workgroup are independent (no barrier)
+    const size_t group = item / (unsigned)n_lt;
+    const int lt = (int)(item % (unsigned)n_lt);
+    const size_t listed0 = group * kBmCullPoses;
+    if (listed0 >= T->n_poses) return;
 
     const int la = lt * 64 + lane;
     const float4 loc = reinterpret_cast<const float4 *>(T->m.lig_local)[la];
     const bool valid = loc.w != 0.f;
-    const Affine A = bm_load_affine(T->rt, pose);
-    float fx, fy, fz;
-    bm_apply(A, loc.x, loc.y, loc.z, fx, fy, fz);
-    const bool inside = fabsf(fx) <= T->m.ubound && fabsf(fy) <= T->m.ubound && fabsf(fz) <= T->m.ubound;
-
-    // An atom outside the frame is more than the cutoff away from every receptor atom (the frame holds the receptor's
-    // box + 16 A): it joins no box; the pairs it still meets inside blocks of its subtile read "miss", as they must.
-    BoxRegs sub = lane_box(valid && inside, fx, fy, fz);
-    box_reduce8(sub);
-    BoxRegs whole = sub;
-    box_reduce64_from8(whole);
-    {   // widen: the f32 positions are within box_pad of the exactly posed ones (and a relative term for huge frames)
-        const float pad = T->m.box_pad;
-        auto widen = [pad](BoxRegs &b) {
-            box_widen(b);
-            b.lox -= pad; b.loy -= pad; b.loz -= pad;
-            b.hix += pad; b.hiy += pad; b.hiz += pad;
-        };
-        widen(sub);
-        widen(whole);
-    }
-    whole.lox = lane63_f32(whole.lox); whole.loy = lane63_f32(whole.loy); whole.loz = lane63_f32(whole.loz);
-    whole.hix = lane63_f32(whole.hix); whole.hiy = lane63_f32(whole.hiy); whole.hiz = lane63_f32(whole.hiz);
-
-    // 64 x 64 tile boxes, 64 receptor tiles per ballot; then the 8 x 8 subtile boxes of every surviving tile
     const int bj = lane & 7;
-    int n_vis = 0;
-    uint32_t tested = 0;
-    for (int base = 0; base < n_rt; base += 64) {
-        bool tile_near = false;
-        if (base + lane < n_rt) tile_near = box_gap2(whole, T->m.rec_tile[base + lane]) <= kBmBoxCut;
-        unsigned long long rtmask = __ballot(tile_near);
-        while (rtmask) {
-            const int RT = base + __ffsll(rtmask) - 1;
-            rtmask &= rtmask - 1;
-            const TiledBox nb = T->m.rec_sub[(size_t)RT * 8 + bj];
-            const unsigned long long smask = __ballot(box_gap2(sub, nb) <= kBmBoxCut);  // bit = ligand subtile (lane >> 3) * 8 + receptor subtile
-            if (smask) {
-                if (lane == 0) {
-                    s_mask[n_vis] = smask;
-                    s_rt[n_vis] = (uint32_t)RT;
+    const float ubound = T->m.ubound, pad = T->m.box_pad;
+    // this lane's receptor tile box (the first 64 tiles; larger receptors load the rest per pose)
+    TiledBox my_tile = TiledBox{INFINITY, INFINITY, INFINITY, 0.f, -INFINITY, -INFINITY, -INFINITY, 0.f};
+    if (lane < n_rt) my_tile = T->m.rec_tile[lane];
+
+    CullAppend pend{0, 0, 0ull, false};   // the previous pose's append of this lane (n_vis <= 64 on this path)
+    Affine pend_A{};
+    size_t pend_slot = 0;
+    auto finish_append = [&]() {
+        if (pend.on) {
+            const size_t tp = (size_t)lt * n_rt + pend.RT;
+            const size_t at = tp * T->cap + pend.idx;
+            T->ent_pose[at] = (uint32_t)(pend_slot / (unsigned)n_lt);
+            T->ent_mask[at] = pend.mask;
+            float4 *ap = reinterpret_cast<float4 *>(T->ent_rt) + at * 3;   // what a pair batch poses the entry with
+            ap[0] = float4{pend_A.r00, pend_A.r01, pend_A.r02, pend_A.tx};
+            ap[1] = float4{pend_A.r10, pend_A.r11, pend_A.r12, pend_A.ty};
+            ap[2] = float4{pend_A.r20, pend_A.r21, pend_A.r22, pend_A.tz};
+            uint32_t rows = 0;   // ligand subtiles with a block in the mask
+#pragma unroll
+            for (int a = 0; a < 8; a++) rows |= ((pend.mask >> (8 * a)) & 0xffull) ? 1u << a : 0u;
+            T->vis_entry[pend_slot * (size_t)n_rt + lane] = (unsigned long long)pend.RT << 40 | (unsigned long long)rows << 32 | pend.idx;
+        }
+        pend.on = false;
+    };
+
+    for (int g = 0; g < kBmCullPoses; g++) {
+        const size_t listed = listed0 + g;
+        if (listed >= T->n_poses) break;
+        const long long pp = bm_pose_of(T, listed);
+        if (pp < 0) continue;
+        const size_t pose = (size_t)pp;
+        const size_t slot = pose * (size_t)n_lt + lt;
+        const Affine A = bm_load_affine(T->rt, pose);
+        float fx, fy, fz;
+        bm_apply(A, loc.x, loc.y, loc.z, fx, fy, fz);
+        const bool inside = fabsf(fx) <= ubound && fabsf(fy) <= ubound && fabsf(fz) <= ubound;
+
+        // An atom outside the frame is more than the cutoff away from every receptor atom (the frame holds the receptor's
+        // box + 16 A): it joins no box; the pairs it still meets inside blocks of its subtile read "miss", as they must.
+        BoxRegs sub = lane_box(valid && inside, fx, fy, fz);
+        box_reduce8(sub);
+        BoxRegs whole = sub;
+        box_reduce64_from8(whole);
+        {   // widen: the f32 positions are within box_pad of the exactly posed ones
+            auto widen = [pad](BoxRegs &b) {
+                box_widen(b);
+                b.lox -= pad; b.loy -= pad; b.loz -= pad;
+                b.hix += pad; b.hiy += pad; b.hiz += pad;
+            };
+            widen(sub);
+            widen(whole);
+        }
+        whole.lox = lane63_f32(whole.lox); whole.loy = lane63_f32(whole.loy); whole.loz = lane63_f32(whole.loz);
+        whole.hix = lane63_f32(whole.hix); whole.hiy = lane63_f32(whole.hiy); whole.hiz = lane63_f32(whole.hiz);
+
+        // 64 x 64 tile boxes, 64 receptor tiles per ballot; then the 8 x 8 subtile boxes of every surviving tile
+        int n_vis = 0;
+        uint32_t tested = 0;
+        for (int base = 0; base < n_rt; base += 64) {
+            bool tile_near = false;
+            if (base == 0) tile_near = lane < n_rt && box_gap2(whole, my_tile) <= kBmBoxCut;
+            else if (base + lane < n_rt) tile_near = box_gap2(whole, T->m.rec_tile[base + lane]) <= kBmBoxCut;
+            unsigned long long rtmask = __ballot(tile_near);
+            while (rtmask) {
+                // four surviving tiles at a time: their subtile boxes are loaded together
+                int RTs[4], nk = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    RTs[k] = rtmask ? base + __ffsll(rtmask) - 1 : RTs[0];
+                    if (rtmask) nk++;
+                    rtmask &= rtmask - 1;
                 }
-                n_vis++;
-                if (COUNT) tested += (uint32_t)__popcll(smask);
+                TiledBox nb[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) nb[k] = T->m.rec_sub[(size_t)RTs[k] * 8 + bj];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k >= nk) break;
+                    const unsigned long long smask = __ballot(box_gap2(sub, nb[k]) <= kBmBoxCut);  // bit = ligand subtile (lane >> 3) * 8 + receptor subtile
+                    if (smask) {
+                        if (lane == 0) {
+                            s_mask[n_vis] = smask;
+                            s_rt[n_vis] = (uint32_t)RTs[k];
+                        }
+                        n_vis++;
+                        if (COUNT) tested += (uint32_t)__popcll(smask);
+                    }
+                }
             }
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // one entry per surviving tile pair, the appends of a wave in one atomic instruction
-    for (int v0 = 0; v0 < n_vis; v0 += 64) {
-        const int v = v0 + lane;
-        if (v < n_vis) {
-            const uint32_t RT = s_rt[v];
-            const size_t tp = (size_t)lt * n_rt + RT;
-            const uint32_t idx = atomicAdd(&T->tp_count[tp], 1u);
-            T->ent_pose[tp * T->cap + idx] = (uint32_t)pose;
-            T->ent_mask[tp * T->cap + idx] = s_mask[v];
-            float4 *ap = reinterpret_cast<float4 *>(T->ent_rt) + (tp * T->cap + idx) * 3;   // what a pair batch poses the entry with
-            ap[0] = float4{A.r00, A.r01, A.r02, A.tx};
-            ap[1] = float4{A.r10, A.r11, A.r12, A.ty};
-            ap[2] = float4{A.r20, A.r21, A.r22, A.tz};
-            T->vis_entry[slot * (size_t)n_rt + v] = RT << 24 | idx;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        finish_append();   // the previous pose's entries: their atomics have had this pose's culling to return
+        // one entry per surviving tile pair, the appends of a wave in one atomic instruction
+        if (lane < n_vis && lane < 64) {
+            pend.RT = s_rt[lane];
+            pend.mask = s_mask[lane];
+            pend.idx = atomicAdd(&T->tp_count[(size_t)lt * n_rt + pend.RT], 1u);
+            pend.on = true;
+        }
+        pend_A = A;
+        pend_slot = slot;
+        for (int v0 = 64; v0 < n_vis; v0 += 64) {   // receptors of more than 64 tiles: the rest at once
+            const int v = v0 + lane;
+            if (v < n_vis) {
+                const uint32_t RT = s_rt[v];
+                const unsigned long long sm = s_mask[v];
+                const size_t tp = (size_t)lt * n_rt + RT;
+                const uint32_t idx = atomicAdd(&T->tp_count[tp], 1u);
+                const size_t at = tp * T->cap + idx;
+                T->ent_pose[at] = (uint32_t)pose;
+                T->ent_mask[at] = sm;
+                float4 *ap = reinterpret_cast<float4 *>(T->ent_rt) + at * 3;
+                ap[0] = float4{A.r00, A.r01, A.r02, A.tx};
+                ap[1] = float4{A.r10, A.r11, A.r12, A.ty};
+                ap[2] = float4{A.r20, A.r21, A.r22, A.tz};
+                uint32_t rows = 0;
+#pragma unroll
+                for (int a = 0; a < 8; a++) rows |= ((sm >> (8 * a)) & 0xffull) ? 1u << a : 0u;
+                T->vis_entry[slot * (size_t)n_rt + v] = (unsigned long long)RT << 40 | (unsigned long long)rows << 32 | idx;
+            }
+        }
+        if (lane == 0) {
+            T->vis_count[slot] = (uint32_t)n_vis;
+            if (COUNT) T->tile_tested[slot] = tested;
         }
     }
-    if (lane == 0) {
-        T->vis_count[slot] = (uint32_t)n_vis;
-        if (COUNT) T->tile_tested[slot] = tested;
-    }
+    finish_append();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -489,10 +564,11 @@ __global__ __launch_bounds__(kBmWaves * 64, 2) void dfire_bm_pairs(const BmLaunc
                 double acc = 0.0;
                 uint32_t cnt = 0;
                 const uint32_t queued_before = queued;
+                // The batch's 32 steps are ONE basic block (the scheduler overlaps the LDS latencies of a group of 8 steps
+                // with the arithmetic of the next); flagged cells are looked for afterwards, in the codes kept in registers.
+                uint32_t w[4][16], wm[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    // a group of 8 steps: all cells, all codes, all table values, then the adds in order; one test for flagged cells
-                    uint32_t w[16];
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
                         const v2f dx = Rx[q] - v2f{lx[i], lx[i]}, dy = Ry[q] - v2f{ly[i], ly[i]}, dz = Rz[q] - v2f{lz[i], lz[i]};
@@ -500,33 +576,45 @@ __global__ __launch_bounds__(kBmWaves * 64, 2) void dfire_bm_pairs(const BmLaunc
                         D = __builtin_elementwise_fma(dy, dy, D);
                         D = __builtin_elementwise_fma(dx, dx, D);
                         const uint32_t c0 = bm_cvt_u32(fminf(D.x, cell_max)), c1 = bm_cvt_u32(fminf(D.y, cell_max));
-                        w[2 * i] = S.lut[c0];
-                        w[2 * i + 1] = S.lut[c1];
+                        w[q][2 * i] = S.lut[c0];
+                        w[q][2 * i + 1] = S.lut[c1];
                     }
-                    uint32_t wm = 0;
+                    // all 16 table values of the group in flight, then the adds in order
+#pragma unroll
+                    for (int k = 0; k < 16; k++) asm("" : "+v"(w[q][k]));   // 32-bit values from here on (no 16-bit detours on the way to the address)
+                    double tv[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) tv[k] = *reinterpret_cast<const double *>(cube + ((k >> 1) * 8 + 2 * q + (k & 1)) * kBmRowBytes + w[q][k]);
+                    wm[q] = 0;
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
-                        asm volatile("" : "+v"(w[2 * i]), "+v"(w[2 * i + 1]));   // 32-bit values from here on (no 16-bit detours on the way to the address)
-                        acc += *reinterpret_cast<const double *>(cube + (i * 8 + 2 * q) * kBmRowBytes + w[2 * i]);
-                        acc += *reinterpret_cast<const double *>(cube + (i * 8 + 2 * q + 1) * kBmRowBytes + w[2 * i + 1]);
+                        acc += tv[2 * i];
+                        acc += tv[2 * i + 1];
                         if (COUNT && Lreal[i])
-                            cnt += (w[2 * i] != 0u && w[2 * i] < kBmFlagged ? 1u : 0u) + (w[2 * i + 1] != 0u && w[2 * i + 1] < kBmFlagged ? 1u : 0u);
-                        const uint32_t m2 = w[2 * i] > w[2 * i + 1] ? w[2 * i] : w[2 * i + 1];
-                        wm = wm > m2 ? wm : m2;
+                            cnt += (w[q][2 * i] != 0u && w[q][2 * i] < kBmFlagged ? 1u : 0u) + (w[q][2 * i + 1] != 0u && w[q][2 * i + 1] < kBmFlagged ? 1u : 0u);
+                        const uint32_t m2 = w[q][2 * i] > w[q][2 * i + 1] ? w[q][2 * i] : w[q][2 * i + 1];
+                        wm[q] = wm[q] > m2 ? wm[q] : m2;
                     }
-                    asm volatile("" : "+v"(acc));   // the group's adds end here (the scheduler would park table values in registers)
-                    if (__builtin_expect(__ballot(wm >= kBmFlagged) != 0ull, 0)) {
-                        // (rare: keep the compiler from preparing any of this outside the branch)
+                    asm("" : "+v"(acc));   // the group's adds end here (the scheduler would park table values in registers)
+                }
+                {
+                    const uint32_t m01 = wm[0] > wm[1] ? wm[0] : wm[1], m23 = wm[2] > wm[3] ? wm[2] : wm[3];
+                    if (__builtin_expect(__ballot((m01 > m23 ? m01 : m23) >= kBmFlagged) != 0ull, 0)) {
+                        // pairs in flagged cells read 0.0 above; queue them for the exact path
                         uint32_t el_here = el;
-                        asm volatile("" : "+v"(el_here));
+                        asm volatile("" : "+v"(el_here));   // (keep the compiler from preparing any of this outside the branch)
 #pragma unroll
-                        for (int k = 0; k < 16; k++) {
-                            const bool f = valid && w[k] >= kBmFlagged;
-                            const unsigned long long m = __ballot(f);
-                            if (m == 0ull) continue;
-                            const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            if (f && at < (uint32_t)kBmQueue) WS.queue[at] = el_here | (uint32_t)((k >> 1) * 8 + 2 * q + (k & 1)) << 10 | (uint32_t)b << 16;
-                            queued += (uint32_t)__popcll(m);
+                        for (int q = 0; q < 4; q++) {
+                            if (__ballot(wm[q] >= kBmFlagged) == 0ull) continue;
+#pragma unroll
+                            for (int k = 0; k < 16; k++) {
+                                const bool f = valid && w[q][k] >= kBmFlagged;
+                                const unsigned long long m = __ballot(f);
+                                if (m == 0ull) continue;
+                                const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                                if (f && at < (uint32_t)kBmQueue) WS.queue[at] = el_here | (uint32_t)((k >> 1) * 8 + 2 * q + (k & 1)) << 10 | (uint32_t)b << 16;
+                                queued += (uint32_t)__popcll(m);
+                            }
                         }
                     }
                 }
@@ -572,44 +660,68 @@ __global__ __launch_bounds__(kBmWaves * 64, 2) void dfire_bm_pairs(const BmLaunc
 // dfire_bm_gather: wave = pose; lanes over the ligand tiles, fixed order, then a fixed tree
 // ---------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ __launch_bounds__(64) void dfire_bm_gather(const BmLaunch launch_arguments) {
+__global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
-    const int lane = threadIdx.x;
+    __shared__ double s_sum[512];
+    __shared__ uint32_t s_cnt[512], s_tested[512];
+    const int tid = threadIdx.x;
     const long long pp = bm_pose_of(T, blockIdx.x);
     if (pp < 0) return;
     const size_t pose = (size_t)pp;
     const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
+    const int a = tid & 7;
     double s = 0.0;
     uint32_t cnt = 0, tested = 0;
-    for (int lt = lane; lt < n_lt; lt += 64) {
+    for (int lt = tid >> 3; lt < n_lt; lt += 64) {   // thread = (ligand tile, ligand subtile a): its entries in the order the culling listed them
         const size_t slot = pose * (size_t)n_lt + lt;
-        if (COUNT) tested += T->tile_tested[slot];
+        if (COUNT && a == 0) tested += T->tile_tested[slot];
         const uint32_t n_vis = T->vis_count[slot];
-        for (uint32_t v = 0; v < n_vis; v++) {
-            const uint32_t ent = T->vis_entry[slot * (size_t)n_rt + v];
-            const size_t tp = (size_t)lt * n_rt + (ent >> 24);
-            const size_t idx = ent & 0xffffffu;
-            const unsigned long long m = T->ent_mask[tp * T->cap + idx];
-            for (int a = 0; a < 8; a++) {
-                if (((m >> (8 * a)) & 0xffull) == 0ull) continue;
-                const size_t pslot = (tp * 8 + (size_t)a) * T->cap + idx;
-                s += T->ent_partial[pslot];
-                if (COUNT) cnt += T->ent_count[pslot];
+        for (uint32_t v0 = 0; v0 < n_vis; v0 += 4) {   // four entries in flight (the loop is bound by the two dependent loads)
+            unsigned long long ent[4];
+            double part[4];
+            uint32_t pc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) ent[k] = v0 + k < n_vis ? T->vis_entry[slot * (size_t)n_rt + v0 + k] : 0ull;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                part[k] = 0.0;
+                pc[k] = 0;
+                if (!((ent[k] >> (32 + a)) & 1ull)) continue;
+                const size_t tp = (size_t)lt * n_rt + (size_t)(ent[k] >> 40);
+                const size_t pslot = (tp * 8 + (size_t)a) * T->cap + (size_t)(ent[k] & 0xffffffffull);
+                part[k] = T->ent_partial[pslot];
+                if (COUNT) pc[k] = T->ent_count[pslot];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                s += part[k];   // (an entry without a block in this row adds 0.0: no bit of the sum changes)
+                cnt += pc[k];
             }
         }
     }
-    s = wave_sum(s);
+    s_sum[tid] = s;
     if (COUNT) {
-        cnt = wave_sum_u32(cnt);
-        tested = wave_sum_u32(tested);
+        s_cnt[tid] = cnt;
+        s_tested[tid] = tested;
     }
-    if (lane == 0) {
-        s += (double)T->exact_fix[pose] * (1.0 / kBmFixScale);
-        T->partial[2 * pose] = s;
+    __syncthreads();
+    for (int half = 256; half > 0; half >>= 1) {   // fixed tree
+        if (tid < half) {
+            s_sum[tid] += s_sum[tid + half];
+            if (COUNT) {
+                s_cnt[tid] += s_cnt[tid + half];
+                s_tested[tid] += s_tested[tid + half];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double total = s_sum[0] + (double)T->exact_fix[pose] * (1.0 / kBmFixScale);
+        T->partial[2 * pose] = total;
         T->partial[2 * pose + 1] = 0.0;
         if (COUNT) {
-            T->count_partial[pose] = cnt + T->exact_count[pose];
-            if (T->tested_partial) T->tested_partial[pose] = tested;
+            T->count_partial[pose] = s_cnt[0] + T->exact_count[pose];
+            if (T->tested_partial) T->tested_partial[pose] = s_tested[0];
             if (T->exact_partial) T->exact_partial[pose] = T->exact_pairs[pose];
         }
     }
@@ -627,10 +739,10 @@ hipError_t launch_bm_pose(const BmLaunch &t, hipStream_t stream) {
 
 hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    const size_t blocks = t.n_poses * (size_t)t.m.lig.n_tiles;
+    const size_t blocks = ((t.n_poses + kBmCullPoses - 1) / kBmCullPoses * (size_t)t.m.lig.n_tiles + kBmCullWaves - 1) / kBmCullWaves;
     if (blocks > 0x7fffffffULL || t.m.rec_n_tiles > 255) return hipErrorInvalidValue;
-    if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_cull<true>), dim3((unsigned)blocks), dim3(64), 0, stream, t);
-    else hipLaunchKernelGGL((dfire_bm_cull<false>), dim3((unsigned)blocks), dim3(64), 0, stream, t);
+    if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_cull<true>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), 0, stream, t);
+    else hipLaunchKernelGGL((dfire_bm_cull<false>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), 0, stream, t);
     return hipGetLastError();
 }
 
@@ -645,8 +757,8 @@ hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
 
 hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_gather<true>), dim3((unsigned)t.n_poses), dim3(64), 0, stream, t);
-    else hipLaunchKernelGGL((dfire_bm_gather<false>), dim3((unsigned)t.n_poses), dim3(64), 0, stream, t);
+    if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_gather<true>), dim3((unsigned)t.n_poses), dim3(512), 0, stream, t);
+    else hipLaunchKernelGGL((dfire_bm_gather<false>), dim3((unsigned)t.n_poses), dim3(512), 0, stream, t);
     return hipGetLastError();
 }
 

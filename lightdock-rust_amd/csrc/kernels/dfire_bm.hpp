@@ -105,7 +105,7 @@ struct BmLaunch {
     int pairs_groups = 0;                  // workgroups of dfire_bm_pairs (0: one per CU of an MI355X)
     unsigned long long *debug = nullptr;   // diagnostics (LIGHTDOCK_BM_DEBUG): per wave of dfire_bm_pairs {start, end (100 MHz), jobs, batches}
     uint32_t *vis_count = nullptr;         // [pose][lig tiles]
-    uint32_t *vis_entry = nullptr;         // [pose][lig tiles][rec tiles]: receptor tile << 24 | entry
+    unsigned long long *vis_entry = nullptr;  // [pose][lig tiles][rec tiles]: receptor tile << 40 | ligand subtiles with a block << 32 | entry
     uint32_t *tile_tested = nullptr;       // [pose][lig tiles]: 8x8 blocks let through (diagnostics) or nullptr
     long long *exact_fix = nullptr;        // [pose], zeroed per launch: exact-path sum in 2^-40 units
     uint32_t *exact_count = nullptr;       // [pose], zeroed per launch, or nullptr

@@ -805,7 +805,7 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     }
     // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x 124 bytes (156 with counts)
     const size_t tile_pairs = (size_t)rec.n_tiles * lig.n_tiles;
-    size_t chunk = ((size_t)4 << 30) / (156 * tile_pairs);
+    size_t chunk = ((size_t)3 << 30) / (156 * tile_pairs);   // two such workspaces exist (two passes in flight)
     chunk = std::max<size_t>(kBmPartEntries, chunk / kBmPartEntries * kBmPartEntries);
     chunk = std::min<size_t>(chunk, (size_t)255 * kBmPartEntries);   // a job names its part in 8 bits
     if (const char *e = std::getenv("LIGHTDOCK_BM_CHUNK")) {
@@ -813,13 +813,30 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
         if (v >= 1) chunk = std::min<size_t>((size_t)v, (size_t)255 * kBmPartEntries);
     }
     bm_chunk_ = chunk;
+    {
+        const char *e = std::getenv("LIGHTDOCK_BM_LANES");
+        if (!(e && std::atoi(e) == 1)) {
+            hip_check(hipStreamCreateWithFlags(&bm_aux_stream_, hipStreamNonBlocking), "hipStreamCreate");
+            hip_check(hipEventCreateWithFlags(&bm_fork_, hipEventDisableTiming), "hipEventCreate");
+            hip_check(hipEventCreateWithFlags(&bm_join_, hipEventDisableTiming), "hipEventCreate");
+        }
+    }
     use_bm_ = true;
+}
+
+// Poses per block-major pass: at most bm_chunk_ (the entry workspace), and at most half the batch so that two passes
+// overlap -- the culling and gathering kernels of one wait on memory while the pair kernel of the other computes.
+size_t Scorer::bm_pass_poses(size_t n) const {
+    if (n < 2 * (size_t)kBmPartEntries) return n;
+    const size_t half = ((n + 1) / 2 + kBmPartEntries - 1) / kBmPartEntries * kBmPartEntries;
+    return std::min(bm_chunk_, half);
 }
 
 void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_t *d_active, bool counts, const uint32_t *d_list,
                     const uint32_t *d_count) {
     const size_t tile_pairs = (size_t)bm_.lig.n_tiles * bm_.rec_n_tiles;
-    const size_t cap = std::min(n, bm_chunk_);
+    const size_t cap = bm_pass_poses(n);
+    const size_t jobs_per_lane = tile_pairs * ((cap + kBmPartEntries - 1) / kBmPartEntries);
     BmLaunch t;
     t.m = bm_;
     t.poses = d_poses;
@@ -829,22 +846,13 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
     t.pose_count = d_list ? d_count : nullptr;
     t.cap = cap;
     t.rt = static_cast<float *>(ws_bm_rt_.ptr);
-    t.tp_count = static_cast<uint32_t *>(ws_bm_tp_count_.ptr);
-    t.job_count = t.tp_count + tile_pairs;
-    t.job_next = t.tp_count + tile_pairs + 1;
-    t.jobs = static_cast<uint32_t *>(ws_bm_jobs_.ptr);
     t.pairs_groups = n_cus_;
-    t.ent_pose = static_cast<uint32_t *>(ws_bm_ent_pose_.ptr);
-    t.ent_mask = static_cast<unsigned long long *>(ws_bm_ent_mask_.ptr);
-    t.ent_rt = static_cast<float *>(ws_bm_ent_rt_.ptr);
-    t.ent_partial = static_cast<double *>(ws_bm_ent_partial_.ptr);
     t.vis_count = static_cast<uint32_t *>(ws_bm_vis_count_.ptr);
-    t.vis_entry = static_cast<uint32_t *>(ws_bm_vis_entry_.ptr);
+    t.vis_entry = static_cast<unsigned long long *>(ws_bm_vis_entry_.ptr);
     t.exact_fix = static_cast<long long *>(ws_bm_exact_fix_.ptr);
     t.flags = static_cast<uint32_t *>(ws_flags_.ptr);
     t.partial = static_cast<double *>(ws_partial_.ptr);
     if (counts) {
-        t.ent_count = static_cast<uint32_t *>(ws_bm_ent_count_.ptr);
         t.tile_tested = static_cast<uint32_t *>(ws_bm_tile_tested_.ptr);
         t.exact_count = static_cast<uint32_t *>(ws_bm_exact_count_.ptr);
         t.exact_pairs = static_cast<uint32_t *>(ws_bm_exact_pairs_.ptr);
@@ -857,14 +865,37 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         ws_bm_debug_.reserve((size_t)n_cus_ * kBmWaves * 8 * sizeof(unsigned long long));
         t.debug = static_cast<unsigned long long *>(ws_bm_debug_.ptr);
     }
-    for (size_t off = 0; off < n; off += cap) {  // poses are independent: passes of at most `cap` poses
+    // Passes of at most `cap` poses (poses are independent), alternating between this handle's stream and a second
+    // one: fork behind what the stream holds so far, join before what follows.
+    const bool two_lanes = n > cap && bm_aux_stream_ != nullptr;
+    if (two_lanes) {
+        hip_check(hipEventRecord(bm_fork_, stream_), "hipEventRecord");
+        hip_check(hipStreamWaitEvent(bm_aux_stream_, bm_fork_, 0), "hipStreamWaitEvent");
+    }
+    int lane = 0;
+    for (size_t off = 0; off < n; off += cap, lane ^= 1) {
+        hipStream_t st = lane && two_lanes ? bm_aux_stream_ : stream_;
+        const size_t w = (size_t)lane;   // workspace set
         t.first = off;
         t.n_poses = std::min(cap, n - off);
-        hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + 2) * sizeof(uint32_t), stream_), "hipMemsetAsync(tile pair counts)");
-        hip_check(launch_bm_pose(t, stream_), "launch dfire_bm_pose");
-        hip_check(launch_bm_cull(t, stream_), "launch dfire_bm_cull");
-        hip_check(launch_bm_pairs(t, stream_), "launch dfire_bm_pairs");
-        hip_check(launch_bm_gather(t, stream_), "launch dfire_bm_gather");
+        t.tp_count = static_cast<uint32_t *>(ws_bm_tp_count_.ptr) + w * (tile_pairs + 2);
+        t.job_count = t.tp_count + tile_pairs;
+        t.job_next = t.tp_count + tile_pairs + 1;
+        t.jobs = static_cast<uint32_t *>(ws_bm_jobs_.ptr) + w * jobs_per_lane;
+        t.ent_pose = static_cast<uint32_t *>(ws_bm_ent_pose_.ptr) + w * tile_pairs * cap;
+        t.ent_mask = static_cast<unsigned long long *>(ws_bm_ent_mask_.ptr) + w * tile_pairs * cap;
+        t.ent_rt = static_cast<float *>(ws_bm_ent_rt_.ptr) + w * tile_pairs * cap * 12;
+        t.ent_partial = static_cast<double *>(ws_bm_ent_partial_.ptr) + w * tile_pairs * 8 * cap;
+        t.ent_count = counts ? static_cast<uint32_t *>(ws_bm_ent_count_.ptr) + w * tile_pairs * 8 * cap : nullptr;
+        hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + 2) * sizeof(uint32_t), st), "hipMemsetAsync(tile pair counts)");
+        hip_check(launch_bm_pose(t, st), "launch dfire_bm_pose");
+        hip_check(launch_bm_cull(t, st), "launch dfire_bm_cull");
+        hip_check(launch_bm_pairs(t, st), "launch dfire_bm_pairs");
+        hip_check(launch_bm_gather(t, st), "launch dfire_bm_gather");
+    }
+    if (two_lanes) {
+        hip_check(hipEventRecord(bm_join_, bm_aux_stream_), "hipEventRecord");
+        hip_check(hipStreamWaitEvent(stream_, bm_join_, 0), "hipStreamWaitEvent");
     }
     if (dbg) {   // diagnostics: wave lifetimes of the last pass, one text line per wave
         hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
@@ -924,6 +955,12 @@ Scorer::~Scorer() {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    if (bm_aux_stream_) {
+        (void)hipStreamSynchronize(bm_aux_stream_);
+        (void)hipStreamDestroy(bm_aux_stream_);
+        (void)hipEventDestroy(bm_fork_);
+        (void)hipEventDestroy(bm_join_);
+    }
     if (own_stream_) {
         (void)hipStreamSynchronize(own_stream_);
         (void)hipStreamDestroy(own_stream_);
@@ -964,19 +1001,19 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
     }
     if (use_bm_) {
         const size_t n = n_poses, n_lt = (size_t)bm_.lig.n_tiles, n_rt = (size_t)bm_.rec_n_tiles, tile_pairs = n_lt * n_rt;
-        const size_t cap = std::min(n, bm_chunk_);
+        const size_t cap = bm_pass_poses(n) * 2;   // two passes in flight (run_bm), each with its own entry workspace
         ws_bm_rt_.reserve(n * 12 * sizeof(float));
-        ws_bm_tp_count_.reserve((tile_pairs + 2) * sizeof(uint32_t));   // + jobs listed, jobs drawn
-        ws_bm_jobs_.reserve(tile_pairs * ((cap + kBmPartEntries - 1) / kBmPartEntries) * sizeof(uint32_t));
+        ws_bm_tp_count_.reserve(2 * (tile_pairs + 2) * sizeof(uint32_t));   // + jobs listed, jobs drawn
+        ws_bm_jobs_.reserve(2 * tile_pairs * ((cap / 2 + kBmPartEntries - 1) / kBmPartEntries) * sizeof(uint32_t));
         ws_bm_ent_pose_.reserve(tile_pairs * cap * sizeof(uint32_t));
         ws_bm_ent_mask_.reserve(tile_pairs * cap * sizeof(unsigned long long));
         ws_bm_ent_rt_.reserve(tile_pairs * cap * 12 * sizeof(float));
         ws_bm_ent_partial_.reserve(tile_pairs * 8 * cap * sizeof(double));
         ws_bm_vis_count_.reserve(n * n_lt * sizeof(uint32_t));
-        ws_bm_vis_entry_.reserve(n * tile_pairs * sizeof(uint32_t));
+        ws_bm_vis_entry_.reserve(n * tile_pairs * sizeof(unsigned long long));
         ws_bm_exact_fix_.reserve(n * sizeof(long long));
         if (counts) {
-            ws_bm_ent_count_.reserve(tile_pairs * 8 * cap * sizeof(uint32_t));
+            ws_bm_ent_count_.reserve(tile_pairs * 8 * cap * sizeof(uint32_t));   // (cap covers both passes in flight)
             ws_bm_tile_tested_.reserve(n * n_lt * sizeof(uint32_t));
             ws_bm_exact_count_.reserve(n * sizeof(uint32_t));
             ws_bm_exact_pairs_.reserve(n * sizeof(uint32_t));

@@ -152,6 +152,9 @@ class Scorer {
     BmModel bm_;
     TiledSoA tiled_lig_soa_;
     size_t bm_chunk_ = 0;      // poses per block-major pass (bounds the entry workspace)
+    size_t bm_pass_poses(size_t n) const;
+    hipStream_t bm_aux_stream_ = nullptr;   // the second of two passes in flight runs here
+    hipEvent_t bm_fork_ = nullptr, bm_join_ = nullptr;
     int n_cus_ = 256;
     DeviceBuffer ws_bm_debug_, ws_bm_jobs_, ws_bm_rt_, ws_bm_tp_count_, ws_bm_ent_pose_, ws_bm_ent_mask_, ws_bm_ent_rt_, ws_bm_ent_partial_, ws_bm_ent_count_, ws_bm_vis_count_,
         ws_bm_vis_entry_, ws_bm_tile_tested_, ws_bm_exact_fix_, ws_bm_exact_count_, ws_bm_exact_pairs_;

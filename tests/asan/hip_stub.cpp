@@ -44,6 +44,8 @@ hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSuppo
 hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
@@ -89,7 +91,7 @@ hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t) {
     if (t.n_poses) {
         t.ent_pose[tile_pairs * t.cap - 1] = 0;
         t.ent_mask[tile_pairs * t.cap - 1] = 0;
-        t.vis_entry[(t.first + t.n_poses) * tile_pairs - 1] = 0;
+        t.vis_entry[(t.first + t.n_poses) * tile_pairs - 1] = 0ull;
         t.vis_count[(t.first + t.n_poses) * (size_t)t.m.lig.n_tiles - 1] = 0;
     }
     return hipSuccess;
