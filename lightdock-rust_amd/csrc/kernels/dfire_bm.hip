@@ -376,10 +376,10 @@ __device__ __noinline__ void bm_drain(BmArgs *T, const BmWaveCtx &W, const uint3
 // A whole batch in f64 (its queue overflowed: the poses of an absurd batch, e.g. molecules on top of each other):
 // item k's 64 pairs across the lanes, summed into lane k's accumulator.
 template <bool COUNT>
-__device__ __noinline__ void bm_exact_batch(BmArgs *T, const BmWaveCtx &W, int b, uint32_t el, int count, int lane, double &acc, uint32_t &cnt) {
-    const int i = lane >> 3, j = lane & 7;
-    const int la = W.ls * 8 + i, ra = W.RT * 64 + b * 8 + j;
-    const bool real = la < T->m.lig.n_real && ra < T->m.rec_n_real;
+__device__ __noinline__ void bm_exact_batch(BmArgs *T, const BmWaveCtx &W, int la0, int b, uint32_t el, int count, int lane, double &acc, uint32_t &cnt) {
+    const int i = lane >> 3, j = lane & 7;   // lanes beyond the job's kBmLig ligand atoms idle
+    const int la = W.ls * 8 + la0 + i, ra = W.RT * 64 + b * 8 + j;
+    const bool real = i < kBmLig && la < T->m.lig.n_real && ra < T->m.rec_n_real;
     acc = 0.0;
     cnt = 0;
     for (int k = 0; k < count; k++) {
@@ -406,7 +406,7 @@ __device__ __noinline__ void bm_exact_batch(BmArgs *T, const BmWaveCtx &W, int b
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(kBmWaves * 64, 2) void dfire_bm_pairs(const BmLaunch launch_arguments) {
+__global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pairs(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
     __shared__ __attribute__((aligned(16))) BmShared S;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -417,10 +417,10 @@ __global__ __launch_bounds__(kBmWaves * 64, 2) void dfire_bm_pairs(const BmLaunc
         for (int i = tid; i < 2 * kBmLutBytes / 16; i += kBmWaves * 64) reinterpret_cast<uint4 *>(S.lut)[i] = reinterpret_cast<const uint4 *>(lut)[i];
     }
     BmWaveShared &WS = S.w[wave];
-    if (lane < 4) reinterpret_cast<uint32_t *>(WS.cube + 64 * kBmRowBytes)[lane] = 0u;   // the zero slot behind the last row
+    if (lane < 4) reinterpret_cast<uint32_t *>(WS.cube + kBmCubeRows * kBmRowBytes)[lane] = 0u;   // the zero slot behind the last row
     __syncthreads();
     const unsigned char *cube = WS.cube;
-    const uint32_t n_jobs = *T->job_count * 8u;
+    const uint32_t n_jobs = *T->job_count * (uint32_t)kBmRows;
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long dbg_jobs = 0, dbg_batches = 0, dbg_t_batch = 0, dbg_t_drain = 0, dbg_t_scan = 0, dbg_drains = 0;
 
@@ -429,8 +429,9 @@ __global__ __launch_bounds__(kBmWaves * 64, 2) void dfire_bm_pairs(const BmLaunc
         if (lane == 0) job = atomicAdd(T->job_next, 1u);
         job = (uint32_t)__builtin_amdgcn_readfirstlane((int)job);
         if (job >= n_jobs) break;
-        const uint32_t jd = T->jobs[job >> 3];
-        const int a = (int)(job & 7u);
+        const uint32_t jd = T->jobs[job / (uint32_t)kBmRows];
+        const int arow = (int)(job % (uint32_t)kBmRows);   // job row of the tile: ligand subtile a, its atoms la0 .. la0 + kBmLig - 1
+        const int a = arow / kBmSplit, la0 = (arow % kBmSplit) * kBmLig;
         const size_t tp = jd >> 8;
         const uint32_t lo = (jd & 255u) * (uint32_t)kBmPartEntries;
         const uint32_t n = T->tp_count[tp];
@@ -464,22 +465,23 @@ __global__ __launch_bounds__(kBmWaves * 64, 2) void dfire_bm_pairs(const BmLaunc
         dbg_jobs++;
 
         // the ligand subtile's local coordinates (uniform)
-        float Lx[8], Ly[8], Lz[8];
-        bool Lreal[8];
+        float Lx[kBmLig], Ly[kBmLig], Lz[kBmLig];
+        bool Lreal[kBmLig];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const float4 v = reinterpret_cast<const float4 *>(T->m.lig_local)[ls * 8 + i];
+        for (int i = 0; i < kBmLig; i++) {
+            const float4 v = reinterpret_cast<const float4 *>(T->m.lig_local)[ls * 8 + la0 + i];
             Lx[i] = v.x; Ly[i] = v.y; Lz[i] = v.z;
             Lreal[i] = v.w != 0.f;
         }
-        // table rows of a block -> LDS: 704 pieces of 16 bytes, 11 LDS-DMA instructions of 1 KiB
-        uint32_t src_lig[11];
+        // table rows of a block -> LDS: kBmCubeRows * 11 pieces of 16 bytes, one LDS-DMA instruction per KiB
+        constexpr int kPieces = kBmCubeRows * 11, kDma = (kPieces + 63) / 64;
+        uint32_t src_lig[kDma];
 #pragma unroll
-        for (int t = 0; t < 11; t++) {
+        for (int t = 0; t < kDma; t++) {
             const int piece = t * 64 + lane, row = piece / 11;
-            src_lig[t] = T->m.lig_rowbase[ls * 8 + (row >> 3)] + (uint32_t)(piece % 11) * 16u;
+            src_lig[t] = piece < kPieces ? T->m.lig_rowbase[ls * 8 + la0 + (row >> 3)] + (uint32_t)(piece % 11) * 16u : 0u;
         }
-        const size_t row_base = (tp * 8 + (size_t)a) * T->cap + lo;
+        const size_t row_base = (tp * kBmRows + (size_t)arow) * T->cap + lo;
         const size_t ent_base = tp * T->cap + lo;
         uint32_t queued = 0;   // wave-uniform
 
@@ -490,10 +492,11 @@ __global__ __launch_bounds__(kBmWaves * 64, 2) void dfire_bm_pairs(const BmLaunc
                 const unsigned char *rows = reinterpret_cast<const unsigned char *>(T->m.rows);
                 const uint32_t my_roff = T->m.rec_rowoff[(size_t)RT * 64 + b * 8 + (lane & 7)];   // lane j (mod 8): receptor atom j's column
 #pragma unroll
-                for (int t = 0; t < 11; t++) {
+                for (int t = 0; t < kDma; t++) {
                     const int row = (t * 64 + lane) / 11;
                     const uint32_t roff = (uint32_t)__shfl((int)my_roff, row & 7, 64);
-                    __builtin_amdgcn_global_load_lds((const global_u32 *)(rows + src_lig[t] + roff), (lds_u32 *)(WS.cube + t * 1024), 16, 0, 0);
+                    if (t * 64 + 63 < kPieces || t * 64 + lane < kPieces)   // (the last KiB may be partial)
+                        __builtin_amdgcn_global_load_lds((const global_u32 *)(rows + src_lig[t] + roff), (lds_u32 *)(WS.cube + t * 1024), 16, 0, 0);
                 }
             }
             // which LUT: the offset rides in the seed of the distance sum (exact: integers far below 2^24)
@@ -514,12 +517,25 @@ __global__ __launch_bounds__(kBmWaves * 64, 2) void dfire_bm_pairs(const BmLaunc
             }
             // receptor subtile b of the tile: 4 pair records, wave-uniform
             const PackedRecPair *rp = T->m.rec_pairs + (size_t)RT * 32 + b * 4;
-            v2f Rx[4], Ry[4], Rz[4];
+            // The block's distance arithmetic has its origin at the centre c of the receptor subtile's box:
+            //   D'' = |l - r|^2 + seed = (|r - c|^2 + seed) + |l - c|^2 - 2 (r - c) . (l - c)
+            // four packed operations per step instead of six (the differences need not be formed), all operands small
+            // enough (below 2^17 for every pair within reach of the cutoff) that the roundings stay inside eps.
+            float cbx, cby, cbz;
+            {
+                const TiledBox sb = T->m.rec_sub[(size_t)RT * 8 + b];
+                cbx = 0.5f * (sb.lox + sb.hix);
+                cby = 0.5f * (sb.loy + sb.hiy);
+                cbz = 0.5f * (sb.loz + sb.hiz);
+            }
+            v2f Rx[4], Ry[4], Rz[4], Rs[4];   // -2 (r - c), and |r - c|^2 + seed
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                Rx[q] = v2f{rp[q].x0, rp[q].x1};
-                Ry[q] = v2f{rp[q].y0, rp[q].y1};
-                Rz[q] = v2f{rp[q].z0, rp[q].z1};
+                const v2f x = v2f{rp[q].x0, rp[q].x1} - v2f{cbx, cbx}, y = v2f{rp[q].y0, rp[q].y1} - v2f{cby, cby}, z = v2f{rp[q].z0, rp[q].z1} - v2f{cbz, cbz};
+                Rs[q] = __builtin_elementwise_fma(x, x, __builtin_elementwise_fma(y, y, __builtin_elementwise_fma(z, z, v2f{seed, seed})));
+                Rx[q] = x * v2f{-2.f, -2.f};
+                Ry[q] = y * v2f{-2.f, -2.f};
+                Rz[q] = z * v2f{-2.f, -2.f};
             }
             // what a lane of a batch needs from memory, loaded one batch ahead
             struct BatchLoads {
@@ -557,62 +573,81 @@ __global__ __launch_bounds__(kBmWaves * 64, 2) void dfire_bm_pairs(const BmLaunc
                 const int count = n_items - done >= 64u ? 64 : (int)(n_items - done);
                 const bool valid = lane < count;
                 const uint32_t el = cur.item & 0x7fffu;
-                const Affine A{cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w, cur.a2.x, cur.a2.y, cur.a2.z, cur.a2.w};
-                float lx[8], ly[8], lz[8];
+                const Affine A{cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w - cbx, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w - cby, cur.a2.x, cur.a2.y, cur.a2.z, cur.a2.w - cbz};
+                float lx[kBmLig], ly[kBmLig], lz[kBmLig], l2[kBmLig];   // l - c and |l - c|^2
 #pragma unroll
-                for (int i = 0; i < 8; i++) bm_apply(A, Lx[i], Ly[i], Lz[i], lx[i], ly[i], lz[i]);
+                for (int i = 0; i < kBmLig; i++) {
+                    bm_apply(A, Lx[i], Ly[i], Lz[i], lx[i], ly[i], lz[i]);
+                    l2[i] = __builtin_fmaf(lx[i], lx[i], __builtin_fmaf(ly[i], ly[i], lz[i] * lz[i]));
+                }
                 double acc = 0.0;
                 uint32_t cnt = 0;
                 const uint32_t queued_before = queued;
-                // The batch's 32 steps are ONE basic block (the scheduler overlaps the LDS latencies of a group of 8 steps
-                // with the arithmetic of the next); flagged cells are looked for afterwards, in the codes kept in registers.
-                uint32_t w[4][16], wm[4];
+                // The batch's steps (ligand atom i x the receptor pair record q, 2 atom pairs each) in groups of 8, all one basic
+                // block (the scheduler overlaps the LDS latencies of a group with the arithmetic of the next); flagged cells are
+                // looked for afterwards, in the codes kept in registers.  Step t of the batch: q = t / kBmLig, i = t % kBmLig.
+                constexpr int kGroups = kBmLig / 2;
+                uint32_t w[kGroups][16], wm[kGroups];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int g = 0; g < kGroups; g++) {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const v2f dx = Rx[q] - v2f{lx[i], lx[i]}, dy = Ry[q] - v2f{ly[i], ly[i]}, dz = Rz[q] - v2f{lz[i], lz[i]};
+                    for (int s8 = 0; s8 < 8; s8++) {
+                        const int t = g * 8 + s8, q = t / kBmLig, i = t % kBmLig;
+#ifdef LD_BM_DIST6   // (A/B: the six-operation form on the same centred coordinates)
+                        const v2f dx = v2f{-0.5f, -0.5f} * Rx[q] - v2f{lx[i], lx[i]}, dy = v2f{-0.5f, -0.5f} * Ry[q] - v2f{ly[i], ly[i]}, dz = v2f{-0.5f, -0.5f} * Rz[q] - v2f{lz[i], lz[i]};
                         v2f D = __builtin_elementwise_fma(dz, dz, v2f{seed, seed});
                         D = __builtin_elementwise_fma(dy, dy, D);
                         D = __builtin_elementwise_fma(dx, dx, D);
+#else
+                        v2f D = Rs[q] + v2f{l2[i], l2[i]};
+                        D = __builtin_elementwise_fma(Rz[q], v2f{lz[i], lz[i]}, D);
+                        D = __builtin_elementwise_fma(Ry[q], v2f{ly[i], ly[i]}, D);
+                        D = __builtin_elementwise_fma(Rx[q], v2f{lx[i], lx[i]}, D);
+#endif
                         const uint32_t c0 = bm_cvt_u32(fminf(D.x, cell_max)), c1 = bm_cvt_u32(fminf(D.y, cell_max));
-                        w[q][2 * i] = S.lut[c0];
-                        w[q][2 * i + 1] = S.lut[c1];
+                        w[g][2 * s8] = S.lut[c0];
+                        w[g][2 * s8 + 1] = S.lut[c1];
                     }
                     // all 16 table values of the group in flight, then the adds in order
 #pragma unroll
-                    for (int k = 0; k < 16; k++) asm("" : "+v"(w[q][k]));   // 32-bit values from here on (no 16-bit detours on the way to the address)
+                    for (int k = 0; k < 16; k++) asm("" : "+v"(w[g][k]));   // 32-bit values from here on (no 16-bit detours on the way to the address)
                     double tv[16];
 #pragma unroll
-                    for (int k = 0; k < 16; k++) tv[k] = *reinterpret_cast<const double *>(cube + ((k >> 1) * 8 + 2 * q + (k & 1)) * kBmRowBytes + w[q][k]);
-                    wm[q] = 0;
+                    for (int k = 0; k < 16; k++) {
+                        const int t = g * 8 + (k >> 1), q = t / kBmLig, i = t % kBmLig;
+                        tv[k] = *reinterpret_cast<const double *>(cube + (i * 8 + 2 * q + (k & 1)) * kBmRowBytes + w[g][k]);
+                    }
+                    wm[g] = 0;
 #pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        acc += tv[2 * i];
-                        acc += tv[2 * i + 1];
-                        if (COUNT && Lreal[i])
-                            cnt += (w[q][2 * i] != 0u && w[q][2 * i] < kBmFlagged ? 1u : 0u) + (w[q][2 * i + 1] != 0u && w[q][2 * i + 1] < kBmFlagged ? 1u : 0u);
-                        const uint32_t m2 = w[q][2 * i] > w[q][2 * i + 1] ? w[q][2 * i] : w[q][2 * i + 1];
-                        wm[q] = wm[q] > m2 ? wm[q] : m2;
+                    for (int s8 = 0; s8 < 8; s8++) {
+                        acc += tv[2 * s8];
+                        acc += tv[2 * s8 + 1];
+                        if (COUNT && Lreal[(g * 8 + s8) % kBmLig])
+                            cnt += (w[g][2 * s8] != 0u && w[g][2 * s8] < kBmFlagged ? 1u : 0u) + (w[g][2 * s8 + 1] != 0u && w[g][2 * s8 + 1] < kBmFlagged ? 1u : 0u);
+                        const uint32_t m2 = w[g][2 * s8] > w[g][2 * s8 + 1] ? w[g][2 * s8] : w[g][2 * s8 + 1];
+                        wm[g] = wm[g] > m2 ? wm[g] : m2;
                     }
                     asm("" : "+v"(acc));   // the group's adds end here (the scheduler would park table values in registers)
                 }
                 {
-                    const uint32_t m01 = wm[0] > wm[1] ? wm[0] : wm[1], m23 = wm[2] > wm[3] ? wm[2] : wm[3];
-                    if (__builtin_expect(__ballot((m01 > m23 ? m01 : m23) >= kBmFlagged) != 0ull, 0)) {
+                    uint32_t wmax = wm[0];
+#pragma unroll
+                    for (int g = 1; g < kGroups; g++) wmax = wmax > wm[g] ? wmax : wm[g];
+                    if (__builtin_expect(__ballot(wmax >= kBmFlagged) != 0ull, 0)) {
                         // pairs in flagged cells read 0.0 above; queue them for the exact path
                         uint32_t el_here = el;
                         asm volatile("" : "+v"(el_here));   // (keep the compiler from preparing any of this outside the branch)
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            if (__ballot(wm[q] >= kBmFlagged) == 0ull) continue;
+                        for (int g = 0; g < kGroups; g++) {
+                            if (__ballot(wm[g] >= kBmFlagged) == 0ull) continue;
 #pragma unroll
                             for (int k = 0; k < 16; k++) {
-                                const bool f = valid && w[q][k] >= kBmFlagged;
+                                const bool f = valid && w[g][k] >= kBmFlagged;
                                 const unsigned long long m = __ballot(f);
                                 if (m == 0ull) continue;
+                                const int t = g * 8 + (k >> 1), q = t / kBmLig, i = t % kBmLig;
                                 const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                                if (f && at < (uint32_t)kBmQueue) WS.queue[at] = el_here | (uint32_t)((k >> 1) * 8 + 2 * q + (k & 1)) << 10 | (uint32_t)b << 16;
+                                if (f && at < (uint32_t)kBmQueue) WS.queue[at] = el_here | (uint32_t)((la0 + i) * 8 + 2 * q + (k & 1)) << 10 | (uint32_t)b << 16;
                                 queued += (uint32_t)__popcll(m);
                             }
                         }
@@ -620,7 +655,7 @@ __global__ __launch_bounds__(kBmWaves * 64, 2) void dfire_bm_pairs(const BmLaunc
                 }
                 if (__builtin_expect(queued > (uint32_t)kBmQueue, 0)) {
                     queued = queued_before;   // forget what this batch queued: all of it again in f64
-                    bm_exact_batch<COUNT>(T, W, b, el, count, lane, acc, cnt);
+                    bm_exact_batch<COUNT>(T, W, la0, b, el, count, lane, acc, cnt);
                 }
                 if (valid) {
                     T->ent_partial[row_base + el] = cur.prev + acc;
@@ -669,12 +704,12 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
     if (pp < 0) return;
     const size_t pose = (size_t)pp;
     const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
-    const int a = tid & 7;
+    const int arow = tid % kBmRows, a = arow / kBmSplit;
     double s = 0.0;
     uint32_t cnt = 0, tested = 0;
-    for (int lt = tid >> 3; lt < n_lt; lt += 64) {   // thread = (ligand tile, ligand subtile a): its entries in the order the culling listed them
+    for (int lt = tid / kBmRows; lt < n_lt; lt += 512 / kBmRows) {   // thread = (ligand tile, job row): its entries in the order the culling listed them
         const size_t slot = pose * (size_t)n_lt + lt;
-        if (COUNT && a == 0) tested += T->tile_tested[slot];
+        if (COUNT && arow == 0) tested += T->tile_tested[slot];
         const uint32_t n_vis = T->vis_count[slot];
         for (uint32_t v0 = 0; v0 < n_vis; v0 += 4) {   // four entries in flight (the loop is bound by the two dependent loads)
             unsigned long long ent[4];
@@ -688,7 +723,7 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
                 pc[k] = 0;
                 if (!((ent[k] >> (32 + a)) & 1ull)) continue;
                 const size_t tp = (size_t)lt * n_rt + (size_t)(ent[k] >> 40);
-                const size_t pslot = (tp * 8 + (size_t)a) * T->cap + (size_t)(ent[k] & 0xffffffffull);
+                const size_t pslot = (tp * kBmRows + (size_t)arow) * T->cap + (size_t)(ent[k] & 0xffffffffull);
                 part[k] = T->ent_partial[pslot];
                 if (COUNT) pc[k] = T->ent_count[pslot];
             }

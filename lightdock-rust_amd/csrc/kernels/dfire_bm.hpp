@@ -43,12 +43,17 @@ constexpr int kBmLutBytes = 14592;           // cells 0 .. 14591: everything bey
 constexpr float kBmCellMax = 14591.0f;
 constexpr int kBmRowSlots = 22;              // slot 0 = 0.0 (miss), slot 1 + b = bin b (0..20; 20 = the read past the row at r = 15.0)
 constexpr int kBmRowBytes = kBmRowSlots * 8;
-constexpr int kBmCubeBytes = 64 * kBmRowBytes + 16;  // + one zero slot behind the last row
+constexpr int kBmLig = 8;                    // ligand atoms per job row: a job walks the blocks (kBmLig ligand atoms x 8 receptor atoms) of one
+                                             // half of a ligand subtile -- half the table rows in LDS per wave, twice the waves per CU
+constexpr int kBmSplit = 8 / kBmLig;         // job rows per ligand subtile
+constexpr int kBmRows = 8 * kBmSplit;        // job rows per ligand tile
+constexpr int kBmCubeRows = kBmLig * 8;
+constexpr int kBmCubeBytes = kBmCubeRows * kBmRowBytes + 16;  // + one zero slot behind the last row
 constexpr uint32_t kBmFlagged = kBmRowBytes;  // LUT code of a flagged cell: slot 0 of the NEXT row = 0.0, above every bin code
 constexpr int kBmTypes = 170;                // 169 DFIRE types + one all-zero type for padding atoms
-constexpr int kBmWaves = 8;                  // waves per dfire_bm_pairs workgroup
+constexpr int kBmWaves = kBmLig == 4 ? 12 : 8;  // waves per dfire_bm_pairs workgroup (one workgroup per CU: what its LDS holds)
 constexpr int kBmPartEntries = 1024;         // entries of a tile pair in one job
-constexpr int kBmQueue = 256;                // per wave: pairs waiting for the exact path
+constexpr int kBmQueue = 128;                // per wave: pairs waiting for the exact path
 constexpr double kBmFixScale = 1099511627776.0;  // 2^40: fixed-point units of the exact path's sum
 
 struct BmModel {
@@ -97,8 +102,8 @@ struct BmLaunch {
     uint32_t *ent_pose = nullptr;          // [tile pair][cap]
     unsigned long long *ent_mask = nullptr;  // [tile pair][cap]
     float *ent_rt = nullptr;               // [tile pair][cap][12]: the entry's pose as the f32 affine map
-    double *ent_partial = nullptr;         // [tile pair][8][cap]
-    uint32_t *ent_count = nullptr;         // [tile pair][8][cap] or nullptr (counting launches)
+    double *ent_partial = nullptr;         // [tile pair][kBmRows][cap]
+    uint32_t *ent_count = nullptr;         // [tile pair][kBmRows][cap] or nullptr (counting launches)
     uint32_t *jobs = nullptr;              // [tile pairs * parts]: tile pair << 8 | part, written by dfire_bm_plan
     uint32_t *job_count = nullptr;         // [2], zeroed per launch: jobs listed, jobs drawn (job_next = job_count + 1)
     uint32_t *job_next = nullptr;

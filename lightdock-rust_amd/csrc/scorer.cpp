@@ -639,11 +639,21 @@ double dfire_bm_pose_error(double ubound, double lig_extent) {
 }
 
 double dfire_bm_error_bound(double ubound, double lig_extent) {
-    const double e_lig = dfire_bm_pose_error(ubound, lig_extent) / std::sqrt(3.0);   // per coordinate
-    const double e_rec = std::ldexp(ubound, -25);
-    const double e_d = e_lig + e_rec + std::ldexp(256.0, -25);       // + the rounding of the difference (below 256 for pairs in range)
-    const double span = std::sqrt(3.0 * 1100.0 * kBmCells);          // |du| + |dv| + |dw| <= sqrt(3) |d|, pairs within 1100 units of 4 d2
-    const double eps = 2.0 * e_d * span + 3.0 * e_d * e_d + 3.0 * std::ldexp(32768.0, -25);   // + three fma roundings of sums below 32768
+    // What dfire_bm_pairs computes: coordinates relative to the centre c of the receptor subtile's box (an f32 constant),
+    //   D'' = (|r - c|^2 + seed) + |l - c|^2 - 2 (r - c) . (l - c)
+    // in f32: 3 + 3 operations for the two squares, one add, three fmas.  For the f32 coordinates this is |l - r|^2 + seed
+    // up to those roundings.  Per coordinate, in record units, for atoms inside the frame (|u| <= U = ubound):
+    auto half_ulp = [](double magnitude) { return std::ldexp(1.0, (int)std::floor(std::log2(magnitude)) - 24); };   // of values below `magnitude`
+    const double reach = kBmKappa * lig_extent;                 // |kappa R x|
+    const double e_lig = std::ldexp(6.0 * reach, -24)          // rounding of the matrix and of the local coordinates
+                         + 2.0 * half_ulp(ubound)               // of the stored translation, and of translation - c
+                         + 3.0 * half_ulp(ubound / 2 + reach);  // of the three fmas: partial sums below |translation - c| + |kappa R x|
+    const double e_rec = half_ulp(ubound) + half_ulp(128.0);    // the record's rounding, and that of r - c
+    const double e_d = e_lig + e_rec;
+    const double span = std::sqrt(3.0 * 1100.0 * kBmCells);     // |du| + |dv| + |dw| <= sqrt(3) |d|, pairs within 1100 units of 4 d2
+    // The ten roundings of the distance arithmetic: every operand and partial sum of such a pair is below 2^17
+    // (|l - c| <= 16.6 A + a subtile's half extent < 45 A = 362 record units; the seed carries the LUT's offset, < 2^15).
+    const double eps = 2.0 * e_d * span + 3.0 * e_d * e_d + 10.0 * half_ulp(131072.0 * 0.999);
     return 2.0 * eps;  // twice the bound, LUT cells
 }
 
@@ -803,9 +813,9 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
                 }
         M.rows = arena_.upload(rows);
     }
-    // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x 124 bytes (156 with counts)
+    // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x (60 + 12 per job row) bytes
     const size_t tile_pairs = (size_t)rec.n_tiles * lig.n_tiles;
-    size_t chunk = ((size_t)3 << 30) / (156 * tile_pairs);   // two such workspaces exist (two passes in flight)
+    size_t chunk = ((size_t)4 << 30) / ((60 + 12 * kBmRows) * tile_pairs);   // two such workspaces exist (two passes in flight)
     chunk = std::max<size_t>(kBmPartEntries, chunk / kBmPartEntries * kBmPartEntries);
     chunk = std::min<size_t>(chunk, (size_t)255 * kBmPartEntries);   // a job names its part in 8 bits
     if (const char *e = std::getenv("LIGHTDOCK_BM_CHUNK")) {
@@ -824,12 +834,12 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     use_bm_ = true;
 }
 
-// Poses per block-major pass: at most bm_chunk_ (the entry workspace), and at most half the batch so that two passes
-// overlap -- the culling and gathering kernels of one wait on memory while the pair kernel of the other computes.
+// Poses per block-major pass: at most bm_chunk_ (the entry workspace).  Batches that need several passes alternate them between two
+// streams: the culling and gathering kernels of one pass wait on memory while the pair kernel of the other computes.
 size_t Scorer::bm_pass_poses(size_t n) const {
-    if (n < 2 * (size_t)kBmPartEntries) return n;
-    const size_t half = ((n + 1) / 2 + kBmPartEntries - 1) / kBmPartEntries * kBmPartEntries;
-    return std::min(bm_chunk_, half);
+    // (Halving a batch that fits one pass so that two passes overlap was measured and lost: 8192 poses of 1k4c as 2 x 4096 on
+    // two streams 3.08 M evaluations/s against 3.43 M in one pass -- each pass pays its own tail of long jobs.)
+    return std::min(n, bm_chunk_);
 }
 
 void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_t *d_active, bool counts, const uint32_t *d_list,
@@ -885,8 +895,8 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         t.ent_pose = static_cast<uint32_t *>(ws_bm_ent_pose_.ptr) + w * tile_pairs * cap;
         t.ent_mask = static_cast<unsigned long long *>(ws_bm_ent_mask_.ptr) + w * tile_pairs * cap;
         t.ent_rt = static_cast<float *>(ws_bm_ent_rt_.ptr) + w * tile_pairs * cap * 12;
-        t.ent_partial = static_cast<double *>(ws_bm_ent_partial_.ptr) + w * tile_pairs * 8 * cap;
-        t.ent_count = counts ? static_cast<uint32_t *>(ws_bm_ent_count_.ptr) + w * tile_pairs * 8 * cap : nullptr;
+        t.ent_partial = static_cast<double *>(ws_bm_ent_partial_.ptr) + w * tile_pairs * kBmRows * cap;
+        t.ent_count = counts ? static_cast<uint32_t *>(ws_bm_ent_count_.ptr) + w * tile_pairs * kBmRows * cap : nullptr;
         hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + 2) * sizeof(uint32_t), st), "hipMemsetAsync(tile pair counts)");
         hip_check(launch_bm_pose(t, st), "launch dfire_bm_pose");
         hip_check(launch_bm_cull(t, st), "launch dfire_bm_cull");
@@ -1008,12 +1018,12 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         ws_bm_ent_pose_.reserve(tile_pairs * cap * sizeof(uint32_t));
         ws_bm_ent_mask_.reserve(tile_pairs * cap * sizeof(unsigned long long));
         ws_bm_ent_rt_.reserve(tile_pairs * cap * 12 * sizeof(float));
-        ws_bm_ent_partial_.reserve(tile_pairs * 8 * cap * sizeof(double));
+        ws_bm_ent_partial_.reserve(tile_pairs * kBmRows * cap * sizeof(double));
         ws_bm_vis_count_.reserve(n * n_lt * sizeof(uint32_t));
         ws_bm_vis_entry_.reserve(n * tile_pairs * sizeof(unsigned long long));
         ws_bm_exact_fix_.reserve(n * sizeof(long long));
         if (counts) {
-            ws_bm_ent_count_.reserve(tile_pairs * 8 * cap * sizeof(uint32_t));   // (cap covers both passes in flight)
+            ws_bm_ent_count_.reserve(tile_pairs * kBmRows * cap * sizeof(uint32_t));   // (cap covers both passes in flight)
             ws_bm_tile_tested_.reserve(n * n_lt * sizeof(uint32_t));
             ws_bm_exact_count_.reserve(n * sizeof(uint32_t));
             ws_bm_exact_pairs_.reserve(n * sizeof(uint32_t));

@@ -2,6 +2,6 @@
 # usage: bash tools/build_variant.sh <name> [-DFLAG ...]
 name=$1; shift
 cd "$(dirname "$0")/../lightdock-rust_amd" && cp lib/liblightdock_hip.so /tmp/ld_keep.so \
- && touch csrc/kernels/dfire_packed.hip csrc/kernels/dfire_tiled.hip csrc/kernels/pose_energy.hip csrc/scorer.cpp && make EXTRA_HIPFLAGS="$*" >/dev/null \
+ && touch csrc/kernels/dfire_bm.hip csrc/kernels/dfire_packed.hip csrc/kernels/dfire_tiled.hip csrc/kernels/pose_energy.hip csrc/scorer.cpp && make EXTRA_HIPFLAGS="$*" >/dev/null \
  && mkdir -p lib/variants && cp lib/liblightdock_hip.so lib/variants/$name.so \
- && touch csrc/kernels/dfire_packed.hip csrc/kernels/dfire_tiled.hip csrc/kernels/pose_energy.hip csrc/scorer.cpp && make >/dev/null && echo built lib/variants/$name.so
+ && touch csrc/kernels/dfire_bm.hip csrc/kernels/dfire_packed.hip csrc/kernels/dfire_tiled.hip csrc/kernels/pose_energy.hip csrc/scorer.cpp && make >/dev/null && echo built lib/variants/$name.so
