@@ -125,6 +125,14 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
 // pose in registers -- its ligand atom, its receptor tile's box -- and the appends of one pose complete while the next
 // pose is culled.
 // ---------------------------------------------------------------------------------------------
+// bit (a * kBmHalves + h): the mask holds a block of ligand subtile a in the h-th part of its row
+__device__ __forceinline__ uint32_t bm_rows_of(unsigned long long mask) {
+    uint32_t rows = 0;
+#pragma unroll
+    for (int k = 0; k < 8 * kBmHalves; k++) rows |= ((mask >> (k * (8 / kBmHalves))) & ((1ull << (8 / kBmHalves)) - 1ull)) ? 1u << k : 0u;
+    return rows;
+}
+
 struct CullAppend {       // one surviving tile pair per lane, waiting for its entry number
     uint32_t idx;         // returned by the atomic
     uint32_t RT;
@@ -170,10 +178,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
             ap[0] = float4{pend_A.r00, pend_A.r01, pend_A.r02, pend_A.tx};
             ap[1] = float4{pend_A.r10, pend_A.r11, pend_A.r12, pend_A.ty};
             ap[2] = float4{pend_A.r20, pend_A.r21, pend_A.r22, pend_A.tz};
-            uint32_t rows = 0;   // ligand subtiles with a block in the mask
-#pragma unroll
-            for (int a = 0; a < 8; a++) rows |= ((pend.mask >> (8 * a)) & 0xffull) ? 1u << a : 0u;
-            T->vis_entry[pend_slot * (size_t)n_rt + lane] = (unsigned long long)pend.RT << 40 | (unsigned long long)rows << 32 | pend.idx;
+            T->vis_entry[pend_slot * (size_t)n_rt + lane] = (unsigned long long)pend.RT << 48 | (unsigned long long)bm_rows_of(pend.mask) << 32 | pend.idx;
         }
         pend.on = false;
     };
@@ -268,10 +273,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                 ap[0] = float4{A.r00, A.r01, A.r02, A.tx};
                 ap[1] = float4{A.r10, A.r11, A.r12, A.ty};
                 ap[2] = float4{A.r20, A.r21, A.r22, A.tz};
-                uint32_t rows = 0;
-#pragma unroll
-                for (int a = 0; a < 8; a++) rows |= ((sm >> (8 * a)) & 0xffull) ? 1u << a : 0u;
-                T->vis_entry[slot * (size_t)n_rt + v] = (unsigned long long)RT << 40 | (unsigned long long)rows << 32 | idx;
+                T->vis_entry[slot * (size_t)n_rt + v] = (unsigned long long)RT << 48 | (unsigned long long)bm_rows_of(sm) << 32 | idx;
             }
         }
         if (lane == 0) {
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
     if (lane < 4) reinterpret_cast<uint32_t *>(WS.cube + kBmCubeRows * kBmRowBytes)[lane] = 0u;   // the zero slot behind the last row
     __syncthreads();
     const unsigned char *cube = WS.cube;
-    const uint32_t n_jobs = *T->job_count * (uint32_t)kBmRows;
+    const uint32_t n_jobs = *T->job_count * (uint32_t)kBmJobRows;
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long dbg_jobs = 0, dbg_batches = 0, dbg_t_batch = 0, dbg_t_drain = 0, dbg_t_scan = 0, dbg_drains = 0;
 
@@ -429,9 +431,11 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
         if (lane == 0) job = atomicAdd(T->job_next, 1u);
         job = (uint32_t)__builtin_amdgcn_readfirstlane((int)job);
         if (job >= n_jobs) break;
-        const uint32_t jd = T->jobs[job / (uint32_t)kBmRows];
-        const int arow = (int)(job % (uint32_t)kBmRows);   // job row of the tile: ligand subtile a, its atoms la0 .. la0 + kBmLig - 1
-        const int a = arow / kBmSplit, la0 = (arow % kBmSplit) * kBmLig;
+        const uint32_t jd = T->jobs[job / (uint32_t)kBmJobRows];
+        const int jrow = (int)(job % (uint32_t)kBmJobRows);   // partial-sum row of the entry: (job row of the tile, part of its blocks)
+        const int arow = jrow / kBmHalves, b_lo = (jrow % kBmHalves) * (8 / kBmHalves);
+        const int a = arow / kBmSplit, la0 = (arow % kBmSplit) * kBmLig;   // ligand subtile a, its atoms la0 .. la0 + kBmLig - 1
+        const uint32_t b_mask = ((1u << (8 / kBmHalves)) - 1u) << b_lo;      // the job's blocks (a, b_lo .. b_lo + 8 / kBmHalves - 1)
         const size_t tp = jd >> 8;
         const uint32_t lo = (jd & 255u) * (uint32_t)kBmPartEntries;
         const uint32_t n = T->tp_count[tp];
@@ -442,6 +446,14 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
         const BmWaveCtx W{tp, ls, RT, lo};
         const bool lig_tracked = T->m.lig_sub_tracked[ls] != 0;
 
+        // What the job's blocks need that does not depend on the entry, for all 8 receptor subtiles of the tile at once (one
+        // latency, together with the masks): lane = (receptor subtile b, atom j).
+        const uint32_t roff_all = T->m.rec_rowoff[(size_t)RT * 64 + lane];           // the atom's column in a table row block
+        float recf[4];                                                                // the tile's 32 pair records, 256 floats
+#pragma unroll
+        for (int k = 0; k < 4; k++) recf[k] = reinterpret_cast<const float *>(T->m.rec_pairs + (size_t)RT * 32)[k * 64 + lane];
+        const TiledBox my_box = T->m.rec_sub[(size_t)RT * 8 + (lane & 7)];           // lane b (mod 8): subtile b's box
+        const uint32_t my_tracked = T->m.rec_sub_tracked[RT * 8 + (lane & 7)];
         uint32_t any_bits = 0;
         {   // the job's block masks: all loads in flight at once
             static_assert(kBmPartEntries == 1024, "16 chunks of 64 entries");
@@ -453,7 +465,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
             }
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const uint32_t bits = (uint32_t)(m[k] >> (8 * a)) & 0xffu;
+                const uint32_t bits = (uint32_t)(m[k] >> (8 * a)) & b_mask;
                 if (k < n_chunks) WS.row_bits[k * 64 + lane] = (unsigned char)bits;
                 any_bits |= bits;
             }
@@ -481,7 +493,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
             const int piece = t * 64 + lane, row = piece / 11;
             src_lig[t] = piece < kPieces ? T->m.lig_rowbase[ls * 8 + la0 + (row >> 3)] + (uint32_t)(piece % 11) * 16u : 0u;
         }
-        const size_t row_base = (tp * kBmRows + (size_t)arow) * T->cap + lo;
+        const size_t row_base = (tp * kBmJobRows + (size_t)jrow) * T->cap + lo;
         const size_t ent_base = tp * T->cap + lo;
         uint32_t queued = 0;   // wave-uniform
 
@@ -490,17 +502,16 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
             {   // stage the block's rows; they land while the entries are scanned
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous block's reads are done
                 const unsigned char *rows = reinterpret_cast<const unsigned char *>(T->m.rows);
-                const uint32_t my_roff = T->m.rec_rowoff[(size_t)RT * 64 + b * 8 + (lane & 7)];   // lane j (mod 8): receptor atom j's column
 #pragma unroll
                 for (int t = 0; t < kDma; t++) {
                     const int row = (t * 64 + lane) / 11;
-                    const uint32_t roff = (uint32_t)__shfl((int)my_roff, row & 7, 64);
+                    const uint32_t roff = (uint32_t)__shfl((int)roff_all, b * 8 + (row & 7), 64);
                     if (t * 64 + 63 < kPieces || t * 64 + lane < kPieces)   // (the last KiB may be partial)
                         __builtin_amdgcn_global_load_lds((const global_u32 *)(rows + src_lig[t] + roff), (lds_u32 *)(WS.cube + t * 1024), 16, 0, 0);
                 }
             }
             // which LUT: the offset rides in the seed of the distance sum (exact: integers far below 2^24)
-            const float lut_base = lig_tracked || T->m.rec_sub_tracked[RT * 8 + b] != 0 ? 0.f : (float)kBmLutBytes;
+            const float lut_base = lig_tracked || __builtin_amdgcn_readlane((int)my_tracked, b) != 0 ? 0.f : (float)kBmLutBytes;
             const float seed = 0.5f + lut_base, cell_max = kBmCellMax + lut_base;
             // ---- the job's entries that hold block (a, b), in entry order
             uint32_t n_items = 0;
@@ -510,28 +521,28 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                 const unsigned long long m = __ballot(act);
                 if (act) {
                     const uint32_t at = n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    const bool first = (bits & ((1u << b) - 1u)) == 0u;   // the entry's first block in this row: nothing to add to yet
+                    const bool first = (bits & ((1u << b) - 1u)) == 0u;   // the entry's first block of this job (bits hold the job's blocks only): nothing to add to yet
                     WS.items[at] = (unsigned short)((uint32_t)(k * 64 + lane) | (first ? 0x8000u : 0u));
                 }
                 n_items += (uint32_t)__popcll(m);
             }
-            // receptor subtile b of the tile: 4 pair records, wave-uniform
-            const PackedRecPair *rp = T->m.rec_pairs + (size_t)RT * 32 + b * 4;
+            // receptor subtile b of the tile: 4 pair records, wave-uniform, out of the registers loaded at the job's start
             // The block's distance arithmetic has its origin at the centre c of the receptor subtile's box:
             //   D'' = |l - r|^2 + seed = (|r - c|^2 + seed) + |l - c|^2 - 2 (r - c) . (l - c)
             // four packed operations per step instead of six (the differences need not be formed), all operands small
             // enough (below 2^17 for every pair within reach of the cutoff) that the roundings stay inside eps.
-            float cbx, cby, cbz;
-            {
-                const TiledBox sb = T->m.rec_sub[(size_t)RT * 8 + b];
-                cbx = 0.5f * (sb.lox + sb.hix);
-                cby = 0.5f * (sb.loy + sb.hiy);
-                cbz = 0.5f * (sb.loz + sb.hiz);
-            }
+            auto lane_f32 = [](float v, int from) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), from)); };
+            const float cbx = 0.5f * (lane_f32(my_box.lox, b) + lane_f32(my_box.hix, b));
+            const float cby = 0.5f * (lane_f32(my_box.loy, b) + lane_f32(my_box.hiy, b));
+            const float cbz = 0.5f * (lane_f32(my_box.loz, b) + lane_f32(my_box.hiz, b));
+            const float rec_here = (b >> 1) == 0 ? recf[0] : (b >> 1) == 1 ? recf[1] : (b >> 1) == 2 ? recf[2] : recf[3];
             v2f Rx[4], Ry[4], Rz[4], Rs[4];   // -2 (r - c), and |r - c|^2 + seed
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const v2f x = v2f{rp[q].x0, rp[q].x1} - v2f{cbx, cbx}, y = v2f{rp[q].y0, rp[q].y1} - v2f{cby, cby}, z = v2f{rp[q].z0, rp[q].z1} - v2f{cbz, cbz};
+                const int at = (b & 1) * 32 + q * 8;   // record q of the subtile: x0 x1 y0 y1 z0 z1 . .
+                const v2f x = v2f{lane_f32(rec_here, at), lane_f32(rec_here, at + 1)} - v2f{cbx, cbx};
+                const v2f y = v2f{lane_f32(rec_here, at + 2), lane_f32(rec_here, at + 3)} - v2f{cby, cby};
+                const v2f z = v2f{lane_f32(rec_here, at + 4), lane_f32(rec_here, at + 5)} - v2f{cbz, cbz};
                 Rs[q] = __builtin_elementwise_fma(x, x, __builtin_elementwise_fma(y, y, __builtin_elementwise_fma(z, z, v2f{seed, seed})));
                 Rx[q] = x * v2f{-2.f, -2.f};
                 Ry[q] = y * v2f{-2.f, -2.f};
@@ -583,73 +594,56 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                 double acc = 0.0;
                 uint32_t cnt = 0;
                 const uint32_t queued_before = queued;
-                // The batch's steps (ligand atom i x the receptor pair record q, 2 atom pairs each) in groups of 8, all one basic
-                // block (the scheduler overlaps the LDS latencies of a group with the arithmetic of the next); flagged cells are
-                // looked for afterwards, in the codes kept in registers.  Step t of the batch: q = t / kBmLig, i = t % kBmLig.
+                // The batch's steps (ligand atom i x the receptor pair record q, 2 atom pairs each) in groups of 8: all cells, all
+                // codes, all table values of a group in flight, then the adds in order and one test for flagged cells.
+                // Step t of the batch: q = t / kBmLig, i = t % kBmLig.
                 constexpr int kGroups = kBmLig / 2;
-                uint32_t w[kGroups][16], wm[kGroups];
 #pragma unroll
                 for (int g = 0; g < kGroups; g++) {
+                    uint32_t w[16];
 #pragma unroll
                     for (int s8 = 0; s8 < 8; s8++) {
                         const int t = g * 8 + s8, q = t / kBmLig, i = t % kBmLig;
-#ifdef LD_BM_DIST6   // (A/B: the six-operation form on the same centred coordinates)
-                        const v2f dx = v2f{-0.5f, -0.5f} * Rx[q] - v2f{lx[i], lx[i]}, dy = v2f{-0.5f, -0.5f} * Ry[q] - v2f{ly[i], ly[i]}, dz = v2f{-0.5f, -0.5f} * Rz[q] - v2f{lz[i], lz[i]};
-                        v2f D = __builtin_elementwise_fma(dz, dz, v2f{seed, seed});
-                        D = __builtin_elementwise_fma(dy, dy, D);
-                        D = __builtin_elementwise_fma(dx, dx, D);
-#else
                         v2f D = Rs[q] + v2f{l2[i], l2[i]};
                         D = __builtin_elementwise_fma(Rz[q], v2f{lz[i], lz[i]}, D);
                         D = __builtin_elementwise_fma(Ry[q], v2f{ly[i], ly[i]}, D);
                         D = __builtin_elementwise_fma(Rx[q], v2f{lx[i], lx[i]}, D);
-#endif
                         const uint32_t c0 = bm_cvt_u32(fminf(D.x, cell_max)), c1 = bm_cvt_u32(fminf(D.y, cell_max));
-                        w[g][2 * s8] = S.lut[c0];
-                        w[g][2 * s8 + 1] = S.lut[c1];
+                        w[2 * s8] = S.lut[c0];
+                        w[2 * s8 + 1] = S.lut[c1];
                     }
-                    // all 16 table values of the group in flight, then the adds in order
 #pragma unroll
-                    for (int k = 0; k < 16; k++) asm("" : "+v"(w[g][k]));   // 32-bit values from here on (no 16-bit detours on the way to the address)
+                    for (int k = 0; k < 16; k++) asm("" : "+v"(w[k]));   // 32-bit values from here on (no 16-bit detours on the way to the address)
                     double tv[16];
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
                         const int t = g * 8 + (k >> 1), q = t / kBmLig, i = t % kBmLig;
-                        tv[k] = *reinterpret_cast<const double *>(cube + (i * 8 + 2 * q + (k & 1)) * kBmRowBytes + w[g][k]);
+                        tv[k] = *reinterpret_cast<const double *>(cube + (i * 8 + 2 * q + (k & 1)) * kBmRowBytes + w[k]);
                     }
-                    wm[g] = 0;
+                    uint32_t wm = 0;
 #pragma unroll
                     for (int s8 = 0; s8 < 8; s8++) {
                         acc += tv[2 * s8];
                         acc += tv[2 * s8 + 1];
                         if (COUNT && Lreal[(g * 8 + s8) % kBmLig])
-                            cnt += (w[g][2 * s8] != 0u && w[g][2 * s8] < kBmFlagged ? 1u : 0u) + (w[g][2 * s8 + 1] != 0u && w[g][2 * s8 + 1] < kBmFlagged ? 1u : 0u);
-                        const uint32_t m2 = w[g][2 * s8] > w[g][2 * s8 + 1] ? w[g][2 * s8] : w[g][2 * s8 + 1];
-                        wm[g] = wm[g] > m2 ? wm[g] : m2;
+                            cnt += (w[2 * s8] != 0u && w[2 * s8] < kBmFlagged ? 1u : 0u) + (w[2 * s8 + 1] != 0u && w[2 * s8 + 1] < kBmFlagged ? 1u : 0u);
+                        const uint32_t m2 = w[2 * s8] > w[2 * s8 + 1] ? w[2 * s8] : w[2 * s8 + 1];
+                        wm = wm > m2 ? wm : m2;
                     }
-                    asm("" : "+v"(acc));   // the group's adds end here (the scheduler would park table values in registers)
-                }
-                {
-                    uint32_t wmax = wm[0];
-#pragma unroll
-                    for (int g = 1; g < kGroups; g++) wmax = wmax > wm[g] ? wmax : wm[g];
-                    if (__builtin_expect(__ballot(wmax >= kBmFlagged) != 0ull, 0)) {
+                    asm volatile("" : "+v"(acc));   // the group's adds end here (the scheduler would park table values in registers)
+                    if (__builtin_expect(__ballot(wm >= kBmFlagged) != 0ull, 0)) {
                         // pairs in flagged cells read 0.0 above; queue them for the exact path
                         uint32_t el_here = el;
                         asm volatile("" : "+v"(el_here));   // (keep the compiler from preparing any of this outside the branch)
 #pragma unroll
-                        for (int g = 0; g < kGroups; g++) {
-                            if (__ballot(wm[g] >= kBmFlagged) == 0ull) continue;
-#pragma unroll
-                            for (int k = 0; k < 16; k++) {
-                                const bool f = valid && w[g][k] >= kBmFlagged;
-                                const unsigned long long m = __ballot(f);
-                                if (m == 0ull) continue;
-                                const int t = g * 8 + (k >> 1), q = t / kBmLig, i = t % kBmLig;
-                                const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                                if (f && at < (uint32_t)kBmQueue) WS.queue[at] = el_here | (uint32_t)((la0 + i) * 8 + 2 * q + (k & 1)) << 10 | (uint32_t)b << 16;
-                                queued += (uint32_t)__popcll(m);
-                            }
+                        for (int k = 0; k < 16; k++) {
+                            const bool f = valid && w[k] >= kBmFlagged;
+                            const unsigned long long m = __ballot(f);
+                            if (m == 0ull) continue;
+                            const int t = g * 8 + (k >> 1), q = t / kBmLig, i = t % kBmLig;
+                            const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                            if (f && at < (uint32_t)kBmQueue) WS.queue[at] = el_here | (uint32_t)((la0 + i) * 8 + 2 * q + (k & 1)) << 10 | (uint32_t)b << 16;
+                            queued += (uint32_t)__popcll(m);
                         }
                     }
                 }
@@ -704,12 +698,12 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
     if (pp < 0) return;
     const size_t pose = (size_t)pp;
     const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
-    const int arow = tid % kBmRows, a = arow / kBmSplit;
+    const int jrow = tid % kBmJobRows, sub_half = jrow / (kBmSplit * kBmHalves) * kBmHalves + jrow % kBmHalves;   // (ligand subtile, part of its blocks)
     double s = 0.0;
     uint32_t cnt = 0, tested = 0;
-    for (int lt = tid / kBmRows; lt < n_lt; lt += 512 / kBmRows) {   // thread = (ligand tile, job row): its entries in the order the culling listed them
+    for (int lt = tid / kBmJobRows; lt < n_lt; lt += 512 / kBmJobRows) {   // thread = (ligand tile, partial-sum row): its entries in the order the culling listed them
         const size_t slot = pose * (size_t)n_lt + lt;
-        if (COUNT && arow == 0) tested += T->tile_tested[slot];
+        if (COUNT && jrow == 0) tested += T->tile_tested[slot];
         const uint32_t n_vis = T->vis_count[slot];
         for (uint32_t v0 = 0; v0 < n_vis; v0 += 4) {   // four entries in flight (the loop is bound by the two dependent loads)
             unsigned long long ent[4];
@@ -721,9 +715,9 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
             for (int k = 0; k < 4; k++) {
                 part[k] = 0.0;
                 pc[k] = 0;
-                if (!((ent[k] >> (32 + a)) & 1ull)) continue;
-                const size_t tp = (size_t)lt * n_rt + (size_t)(ent[k] >> 40);
-                const size_t pslot = (tp * kBmRows + (size_t)arow) * T->cap + (size_t)(ent[k] & 0xffffffffull);
+                if (!((ent[k] >> (32 + sub_half)) & 1ull)) continue;
+                const size_t tp = (size_t)lt * n_rt + (size_t)(ent[k] >> 48);
+                const size_t pslot = (tp * kBmJobRows + (size_t)jrow) * T->cap + (size_t)(ent[k] & 0xffffffffull);
                 part[k] = T->ent_partial[pslot];
                 if (COUNT) pc[k] = T->ent_count[pslot];
             }

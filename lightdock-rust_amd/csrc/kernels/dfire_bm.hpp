@@ -48,6 +48,11 @@ constexpr int kBmLig = 8;                    // ligand atoms per job row: a job 
 constexpr int kBmSplit = 8 / kBmLig;         // job rows per ligand subtile
 constexpr int kBmRows = 8 * kBmSplit;        // job rows per ligand tile
 constexpr int kBmCubeRows = kBmLig * 8;
+#ifndef LD_BM_HALVES
+#define LD_BM_HALVES 1
+#endif
+constexpr int kBmHalves = LD_BM_HALVES;                 // a job walks 8 / kBmHalves of its row's blocks: shorter jobs, a shorter tail of the launch
+constexpr int kBmJobRows = kBmRows * kBmHalves;   // partial sums per entry
 constexpr int kBmCubeBytes = kBmCubeRows * kBmRowBytes + 16;  // + one zero slot behind the last row
 constexpr uint32_t kBmFlagged = kBmRowBytes;  // LUT code of a flagged cell: slot 0 of the NEXT row = 0.0, above every bin code
 constexpr int kBmTypes = 170;                // 169 DFIRE types + one all-zero type for padding atoms
@@ -102,15 +107,15 @@ struct BmLaunch {
     uint32_t *ent_pose = nullptr;          // [tile pair][cap]
     unsigned long long *ent_mask = nullptr;  // [tile pair][cap]
     float *ent_rt = nullptr;               // [tile pair][cap][12]: the entry's pose as the f32 affine map
-    double *ent_partial = nullptr;         // [tile pair][kBmRows][cap]
-    uint32_t *ent_count = nullptr;         // [tile pair][kBmRows][cap] or nullptr (counting launches)
+    double *ent_partial = nullptr;         // [tile pair][kBmJobRows][cap]
+    uint32_t *ent_count = nullptr;         // [tile pair][kBmJobRows][cap] or nullptr (counting launches)
     uint32_t *jobs = nullptr;              // [tile pairs * parts]: tile pair << 8 | part, written by dfire_bm_plan
     uint32_t *job_count = nullptr;         // [2], zeroed per launch: jobs listed, jobs drawn (job_next = job_count + 1)
     uint32_t *job_next = nullptr;
     int pairs_groups = 0;                  // workgroups of dfire_bm_pairs (0: one per CU of an MI355X)
     unsigned long long *debug = nullptr;   // diagnostics (LIGHTDOCK_BM_DEBUG): per wave of dfire_bm_pairs {start, end (100 MHz), jobs, batches}
     uint32_t *vis_count = nullptr;         // [pose][lig tiles]
-    unsigned long long *vis_entry = nullptr;  // [pose][lig tiles][rec tiles]: receptor tile << 40 | ligand subtiles with a block << 32 | entry
+    unsigned long long *vis_entry = nullptr;  // [pose][lig tiles][rec tiles]: receptor tile << 48 | (ligand subtile, half of its blocks) pairs with a block << 32 | entry
     uint32_t *tile_tested = nullptr;       // [pose][lig tiles]: 8x8 blocks let through (diagnostics) or nullptr
     long long *exact_fix = nullptr;        // [pose], zeroed per launch: exact-path sum in 2^-40 units
     uint32_t *exact_count = nullptr;       // [pose], zeroed per launch, or nullptr

@@ -815,7 +815,7 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     }
     // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x (60 + 12 per job row) bytes
     const size_t tile_pairs = (size_t)rec.n_tiles * lig.n_tiles;
-    size_t chunk = ((size_t)4 << 30) / ((60 + 12 * kBmRows) * tile_pairs);   // two such workspaces exist (two passes in flight)
+    size_t chunk = ((size_t)4 << 30) / ((60 + 12 * kBmJobRows) * tile_pairs);   // two such workspaces exist (two passes in flight)
     chunk = std::max<size_t>(kBmPartEntries, chunk / kBmPartEntries * kBmPartEntries);
     chunk = std::min<size_t>(chunk, (size_t)255 * kBmPartEntries);   // a job names its part in 8 bits
     if (const char *e = std::getenv("LIGHTDOCK_BM_CHUNK")) {
@@ -895,8 +895,8 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         t.ent_pose = static_cast<uint32_t *>(ws_bm_ent_pose_.ptr) + w * tile_pairs * cap;
         t.ent_mask = static_cast<unsigned long long *>(ws_bm_ent_mask_.ptr) + w * tile_pairs * cap;
         t.ent_rt = static_cast<float *>(ws_bm_ent_rt_.ptr) + w * tile_pairs * cap * 12;
-        t.ent_partial = static_cast<double *>(ws_bm_ent_partial_.ptr) + w * tile_pairs * kBmRows * cap;
-        t.ent_count = counts ? static_cast<uint32_t *>(ws_bm_ent_count_.ptr) + w * tile_pairs * kBmRows * cap : nullptr;
+        t.ent_partial = static_cast<double *>(ws_bm_ent_partial_.ptr) + w * tile_pairs * kBmJobRows * cap;
+        t.ent_count = counts ? static_cast<uint32_t *>(ws_bm_ent_count_.ptr) + w * tile_pairs * kBmJobRows * cap : nullptr;
         hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + 2) * sizeof(uint32_t), st), "hipMemsetAsync(tile pair counts)");
         hip_check(launch_bm_pose(t, st), "launch dfire_bm_pose");
         hip_check(launch_bm_cull(t, st), "launch dfire_bm_cull");
@@ -1018,12 +1018,12 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         ws_bm_ent_pose_.reserve(tile_pairs * cap * sizeof(uint32_t));
         ws_bm_ent_mask_.reserve(tile_pairs * cap * sizeof(unsigned long long));
         ws_bm_ent_rt_.reserve(tile_pairs * cap * 12 * sizeof(float));
-        ws_bm_ent_partial_.reserve(tile_pairs * kBmRows * cap * sizeof(double));
+        ws_bm_ent_partial_.reserve(tile_pairs * kBmJobRows * cap * sizeof(double));
         ws_bm_vis_count_.reserve(n * n_lt * sizeof(uint32_t));
         ws_bm_vis_entry_.reserve(n * tile_pairs * sizeof(unsigned long long));
         ws_bm_exact_fix_.reserve(n * sizeof(long long));
         if (counts) {
-            ws_bm_ent_count_.reserve(tile_pairs * kBmRows * cap * sizeof(uint32_t));   // (cap covers both passes in flight)
+            ws_bm_ent_count_.reserve(tile_pairs * kBmJobRows * cap * sizeof(uint32_t));   // (cap covers both passes in flight)
             ws_bm_tile_tested_.reserve(n * n_lt * sizeof(uint32_t));
             ws_bm_exact_count_.reserve(n * sizeof(uint32_t));
             ws_bm_exact_pairs_.reserve(n * sizeof(uint32_t));

@@ -98,7 +98,7 @@ hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t) {
 }
 hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t) {
     const size_t tile_pairs = (size_t)t.m.lig.n_tiles * t.m.rec_n_tiles;
-    if (t.n_poses) t.ent_partial[tile_pairs * kBmRows * t.cap - 1] = 0.0;
+    if (t.n_poses) t.ent_partial[tile_pairs * kBmJobRows * t.cap - 1] = 0.0;
     return hipSuccess;
 }
 hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t) {
