@@ -375,38 +375,6 @@ __device__ __noinline__ void bm_drain(BmArgs *T, const BmWaveCtx &W, const uint3
     }
 }
 
-// A whole batch in f64 (its queue overflowed: the poses of an absurd batch, e.g. molecules on top of each other):
-// item k's 64 pairs across the lanes, summed into lane k's accumulator.
-template <bool COUNT>
-__device__ __noinline__ void bm_exact_batch(BmArgs *T, const BmWaveCtx &W, int la0, int b, uint32_t el, int count, int lane, double &acc, uint32_t &cnt) {
-    const int i = lane >> 3, j = lane & 7;   // lanes beyond the job's kBmLig ligand atoms idle
-    const int la = W.ls * 8 + la0 + i, ra = W.RT * 64 + b * 8 + j;
-    const bool real = i < kBmLig && la < T->m.lig.n_real && ra < T->m.rec_n_real;
-    acc = 0.0;
-    cnt = 0;
-    for (int k = 0; k < count; k++) {
-        const size_t e = W.lo + (size_t)__builtin_amdgcn_readlane((int)el, k);
-        const size_t pose = T->ent_pose[W.tp * T->cap + e];
-        double v = 0.0;
-        uint32_t c = 0;
-        if (real) {
-            const ExactCtx ex = bm_exact_ctx(T, pose);
-            const Vec3 p = pose_ligand_atom(bm_ligand(T), 0, 0, T->poses + pose * T->stride, la);
-            v = exact_pair(ex, p, T->m.lig.tindex[la], la, ra, c);
-        }
-        v = wave_sum(v);
-        v = __shfl(v, 0, 64);
-        if (COUNT) {
-            c = wave_sum_u32(c);
-            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-        }
-        if (lane == k) {
-            acc = v;
-            cnt = c;
-        }
-    }
-}
-
 template <bool COUNT>
 __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pairs(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
@@ -593,7 +561,6 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                 }
                 double acc = 0.0;
                 uint32_t cnt = 0;
-                const uint32_t queued_before = queued;
                 // The batch's steps (ligand atom i x the receptor pair record q, 2 atom pairs each) in groups of 8: all cells, all
                 // codes, all table values of a group in flight, then the adds in order and one test for flagged cells.
                 // Step t of the batch: q = t / kBmLig, i = t % kBmLig.
@@ -640,29 +607,23 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                             const bool f = valid && w[k] >= kBmFlagged;
                             const unsigned long long m = __ballot(f);
                             if (m == 0ull) continue;
+                            if (queued > (uint32_t)kBmQueue - 64u) {   // room for 64 more, always: a pose's sum never depends on its batch
+                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                                bm_drain<COUNT>(T, W, WS.queue, queued, lane);
+                                queued = 0;
+                            }
                             const int t = g * 8 + (k >> 1), q = t / kBmLig, i = t % kBmLig;
                             const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            if (f && at < (uint32_t)kBmQueue) WS.queue[at] = el_here | (uint32_t)((la0 + i) * 8 + 2 * q + (k & 1)) << 10 | (uint32_t)b << 16;
+                            if (f) WS.queue[at] = el_here | (uint32_t)((la0 + i) * 8 + 2 * q + (k & 1)) << 10 | (uint32_t)b << 16;
                             queued += (uint32_t)__popcll(m);
                         }
                     }
-                }
-                if (__builtin_expect(queued > (uint32_t)kBmQueue, 0)) {
-                    queued = queued_before;   // forget what this batch queued: all of it again in f64
-                    bm_exact_batch<COUNT>(T, W, la0, b, el, count, lane, acc, cnt);
                 }
                 if (valid) {
                     T->ent_partial[row_base + el] = cur.prev + acc;
                     if (COUNT) T->ent_count[row_base + el] = cur.prev_cnt + cnt;
                 }
                 if (T->debug) dbg_t_batch += __builtin_amdgcn_s_memrealtime() - dbg_tb;
-                if (queued > (uint32_t)kBmQueue / 2) {
-                    const unsigned long long td = T->debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    bm_drain<COUNT>(T, W, WS.queue, queued, lane);
-                    queued = 0;
-                    if (T->debug) { dbg_t_drain += __builtin_amdgcn_s_memrealtime() - td; dbg_drains++; }
-                }
             }
         }
         if (queued) {
