@@ -22,7 +22,7 @@ typedef const __attribute__((address_space(4))) BmLaunch BmArgs;
 #define LD_BM_ARGS ((BmArgs *)__builtin_amdgcn_kernarg_segment_ptr())
 
 constexpr int kBmCullWaves = 4;   // independent waves per dfire_bm_cull workgroup
-constexpr int kBmCullPoses = 1;   // poses a wave of dfire_bm_cull walks with its ligand tile
+constexpr int kBmCullPoses = 8;   // poses a wave of dfire_bm_cull walks with its ligand tile
 constexpr float kBmBoxCut = 14400.0f * 1.00005f;  // (8 * 15 A)^2 in record units, padded for the rounding of the box test
 
 __device__ __forceinline__ uint32_t bm_cvt_u32(float f) {  // v_cvt_u32_f32 saturates: negative and NaN -> 0
@@ -120,10 +120,10 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
 }
 
 // ---------------------------------------------------------------------------------------------
-// dfire_bm_cull: wave = (ligand tile, kBmCullPoses consecutive poses of the launch).  The kernel is bound by memory
-// latency (a handful of dependent loads and one returning atomic per pose), so a wave keeps what does not depend on the
-// pose in registers -- its ligand atom, its receptor tile's box -- and the appends of one pose complete while the next
-// pose is culled.
+// dfire_bm_cull: wave = (ligand tile, kBmCullPoses consecutive poses of the launch).  Phase 1, pose by pose: the tile's
+// atoms posed in f32, boxes, the 64 x 64 and 8 x 8 box tests; the block masks go to LDS.  Phase 2, lane = receptor
+// tile: ONE atomic per tile pair for all the poses of the wave (the lists of a small complex have few heads: one
+// returning atomic per pose and tile pair serialises on them), then the entries.
 // ---------------------------------------------------------------------------------------------
 // bit (a * kBmHalves + h): the mask holds a block of ligand subtile a in the h-th part of its row
 __device__ __forceinline__ uint32_t bm_rows_of(unsigned long long mask) {
@@ -133,23 +133,14 @@ __device__ __forceinline__ uint32_t bm_rows_of(unsigned long long mask) {
     return rows;
 }
 
-struct CullAppend {       // one surviving tile pair per lane, waiting for its entry number
-    uint32_t idx;         // returned by the atomic
-    uint32_t RT;
-    unsigned long long mask;
-    bool on;
-};
-
 template <bool COUNT>
 __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
-    __shared__ unsigned long long s_mask_all[kBmCullWaves][256];
-    __shared__ uint32_t s_rt_all[kBmCullWaves][256];
+    extern __shared__ unsigned long long s_cull[];   // [wave][pose of the wave][receptor tile]: block mask, 0 = not within reach
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    unsigned long long *s_mask = s_mask_all[wave];
-    uint32_t *s_rt = s_rt_all[wave];
     const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
+    unsigned long long *s_mask = s_cull + (size_t)wave * kBmCullPoses * n_rt;
     const size_t item = (size_t)blockIdx.x * kBmCullWaves + wave;   // the waves of a workgroup are independent (no barrier)
     const size_t group = item / (unsigned)n_lt;
     const int lt = (int)(item % (unsigned)n_lt);
@@ -164,32 +155,16 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     // this lane's receptor tile box (the first 64 tiles; larger receptors load the rest per pose)
     TiledBox my_tile = TiledBox{INFINITY, INFINITY, INFINITY, 0.f, -INFINITY, -INFINITY, -INFINITY, 0.f};
     if (lane < n_rt) my_tile = T->m.rec_tile[lane];
+    for (int k = lane; k < kBmCullPoses * n_rt; k += 64) s_mask[k] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-    CullAppend pend{0, 0, 0ull, false};   // the previous pose's append of this lane (n_vis <= 64 on this path)
-    Affine pend_A{};
-    size_t pend_slot = 0;
-    auto finish_append = [&]() {
-        if (pend.on) {
-            const size_t tp = (size_t)lt * n_rt + pend.RT;
-            const size_t at = tp * T->cap + pend.idx;
-            T->ent_pose[at] = (uint32_t)(pend_slot / (unsigned)n_lt);
-            T->ent_mask[at] = pend.mask;
-            float4 *ap = reinterpret_cast<float4 *>(T->ent_rt) + at * 3;   // what a pair batch poses the entry with
-            ap[0] = float4{pend_A.r00, pend_A.r01, pend_A.r02, pend_A.tx};
-            ap[1] = float4{pend_A.r10, pend_A.r11, pend_A.r12, pend_A.ty};
-            ap[2] = float4{pend_A.r20, pend_A.r21, pend_A.r22, pend_A.tz};
-            T->vis_entry[pend_slot * (size_t)n_rt + lane] = (unsigned long long)pend.RT << 48 | (unsigned long long)bm_rows_of(pend.mask) << 32 | pend.idx;
-        }
-        pend.on = false;
-    };
-
+    long long pose_of[kBmCullPoses];   // wave-uniform
+#pragma unroll
     for (int g = 0; g < kBmCullPoses; g++) {
         const size_t listed = listed0 + g;
-        if (listed >= T->n_poses) break;
-        const long long pp = bm_pose_of(T, listed);
-        if (pp < 0) continue;
-        const size_t pose = (size_t)pp;
-        const size_t slot = pose * (size_t)n_lt + lt;
+        pose_of[g] = listed < T->n_poses ? bm_pose_of(T, listed) : -1;
+        if (pose_of[g] < 0) continue;
+        const size_t pose = (size_t)pose_of[g];
         const Affine A = bm_load_affine(T->rt, pose);
         float fx, fy, fz;
         bm_apply(A, loc.x, loc.y, loc.z, fx, fy, fz);
@@ -214,7 +189,6 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         whole.hix = lane63_f32(whole.hix); whole.hiy = lane63_f32(whole.hiy); whole.hiz = lane63_f32(whole.hiz);
 
         // 64 x 64 tile boxes, 64 receptor tiles per ballot; then the 8 x 8 subtile boxes of every surviving tile
-        int n_vis = 0;
         uint32_t tested = 0;
         for (int base = 0; base < n_rt; base += 64) {
             bool tile_near = false;
@@ -237,51 +211,57 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                 for (int k = 0; k < 4; k++) {
                     if (k >= nk) break;
                     const unsigned long long smask = __ballot(box_gap2(sub, nb[k]) <= kBmBoxCut);  // bit = ligand subtile (lane >> 3) * 8 + receptor subtile
-                    if (smask) {
-                        if (lane == 0) {
-                            s_mask[n_vis] = smask;
-                            s_rt[n_vis] = (uint32_t)RTs[k];
-                        }
-                        n_vis++;
-                        if (COUNT) tested += (uint32_t)__popcll(smask);
-                    }
+                    if (smask && lane == 0) s_mask[g * n_rt + RTs[k]] = smask;
+                    if (COUNT) tested += (uint32_t)__popcll(smask);
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        finish_append();   // the previous pose's entries: their atomics have had this pose's culling to return
-        // one entry per surviving tile pair, the appends of a wave in one atomic instruction
-        if (lane < n_vis && lane < 64) {
-            pend.RT = s_rt[lane];
-            pend.mask = s_mask[lane];
-            pend.idx = atomicAdd(&T->tp_count[(size_t)lt * n_rt + pend.RT], 1u);
-            pend.on = true;
+        if (COUNT && lane == 0) T->tile_tested[pose * (size_t)n_lt + lt] = tested;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // ---- phase 2: lane = receptor tile
+    uint32_t n_vis[kBmCullPoses];   // per pose: surviving tiles listed so far (wave-uniform)
+#pragma unroll
+    for (int g = 0; g < kBmCullPoses; g++) n_vis[g] = 0;
+    for (int base = 0; base < n_rt; base += 64) {
+        const int RT = base + lane;
+        const size_t tp = (size_t)lt * n_rt + (RT < n_rt ? RT : 0);
+        unsigned long long mk[kBmCullPoses];
+        uint32_t k = 0;
+#pragma unroll
+        for (int g = 0; g < kBmCullPoses; g++) {
+            mk[g] = RT < n_rt && pose_of[g] >= 0 ? s_mask[g * n_rt + RT] : 0ull;
+            k += mk[g] ? 1u : 0u;
         }
-        pend_A = A;
-        pend_slot = slot;
-        for (int v0 = 64; v0 < n_vis; v0 += 64) {   // receptors of more than 64 tiles: the rest at once
-            const int v = v0 + lane;
-            if (v < n_vis) {
-                const uint32_t RT = s_rt[v];
-                const unsigned long long sm = s_mask[v];
-                const size_t tp = (size_t)lt * n_rt + RT;
-                const uint32_t idx = atomicAdd(&T->tp_count[tp], 1u);
+        uint32_t idx = k ? atomicAdd(&T->tp_count[tp], k) : 0u;
+#pragma unroll
+        for (int g = 0; g < kBmCullPoses; g++) {
+            const unsigned long long live = __ballot(mk[g] != 0ull);
+            if (pose_of[g] < 0 || live == 0ull) continue;
+            const size_t pose = (size_t)pose_of[g];
+            const size_t slot = pose * (size_t)n_lt + lt;
+            if (mk[g]) {
+                const Affine A = bm_load_affine(T->rt, pose);   // (uniform; what a pair batch poses the entry with)
                 const size_t at = tp * T->cap + idx;
                 T->ent_pose[at] = (uint32_t)pose;
-                T->ent_mask[at] = sm;
+                T->ent_mask[at] = mk[g];
                 float4 *ap = reinterpret_cast<float4 *>(T->ent_rt) + at * 3;
                 ap[0] = float4{A.r00, A.r01, A.r02, A.tx};
                 ap[1] = float4{A.r10, A.r11, A.r12, A.ty};
                 ap[2] = float4{A.r20, A.r21, A.r22, A.tz};
-                T->vis_entry[slot * (size_t)n_rt + v] = (unsigned long long)RT << 48 | (unsigned long long)bm_rows_of(sm) << 32 | idx;
+                const uint32_t v = n_vis[g] + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+                T->vis_entry[slot * (size_t)n_rt + v] = (unsigned long long)RT << 48 | (unsigned long long)bm_rows_of(mk[g]) << 32 | idx;
+                idx++;
             }
-        }
-        if (lane == 0) {
-            T->vis_count[slot] = (uint32_t)n_vis;
-            if (COUNT) T->tile_tested[slot] = tested;
+            n_vis[g] += (uint32_t)__popcll(live);
         }
     }
-    finish_append();
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < kBmCullPoses; g++)
+            if (pose_of[g] >= 0) T->vis_count[(size_t)pose_of[g] * n_lt + lt] = n_vis[g];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -655,14 +635,20 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
     __shared__ double s_sum[512];
     __shared__ uint32_t s_cnt[512], s_tested[512];
     const int tid = threadIdx.x;
-    const long long pp = bm_pose_of(T, blockIdx.x);
-    if (pp < 0) return;
-    const size_t pose = (size_t)pp;
     const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
-    const int jrow = tid % kBmJobRows, sub_half = jrow / (kBmSplit * kBmHalves) * kBmHalves + jrow % kBmHalves;   // (ligand subtile, part of its blocks)
+    // a workgroup holds 512 / span poses, span = the power of two that covers a pose's (ligand tile, partial-sum row) pairs
+    const int rows = n_lt * kBmJobRows;
+    int span = kBmJobRows;
+    while (span < rows && span < 512) span <<= 1;
+    const int per_wg = 512 / span, sub = tid / span, r0 = tid % span;
+    const size_t listed = (size_t)blockIdx.x * per_wg + sub;
+    const long long pp = listed < T->n_poses ? bm_pose_of(T, listed) : -1;
+    const size_t pose = pp < 0 ? 0 : (size_t)pp;
     double s = 0.0;
     uint32_t cnt = 0, tested = 0;
-    for (int lt = tid / kBmJobRows; lt < n_lt; lt += 512 / kBmJobRows) {   // thread = (ligand tile, partial-sum row): its entries in the order the culling listed them
+    for (int r = r0; pp >= 0 && r < rows; r += span) {   // thread = (ligand tile, partial-sum row): its entries in the order the culling listed them
+        const int lt = r / kBmJobRows, jrow = r % kBmJobRows;
+        const int sub_half = jrow / (kBmSplit * kBmHalves) * kBmHalves + jrow % kBmHalves;   // (ligand subtile, part of its blocks)
         const size_t slot = pose * (size_t)n_lt + lt;
         if (COUNT && jrow == 0) tested += T->tile_tested[slot];
         const uint32_t n_vis = T->vis_count[slot];
@@ -695,8 +681,8 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
         s_tested[tid] = tested;
     }
     __syncthreads();
-    for (int half = 256; half > 0; half >>= 1) {   // fixed tree
-        if (tid < half) {
+    for (int half = span >> 1; half > 0; half >>= 1) {   // fixed tree, per pose
+        if (r0 < half) {
             s_sum[tid] += s_sum[tid + half];
             if (COUNT) {
                 s_cnt[tid] += s_cnt[tid + half];
@@ -705,13 +691,13 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        const double total = s_sum[0] + (double)T->exact_fix[pose] * (1.0 / kBmFixScale);
+    if (r0 == 0 && pp >= 0) {
+        const double total = s_sum[tid] + (double)T->exact_fix[pose] * (1.0 / kBmFixScale);
         T->partial[2 * pose] = total;
         T->partial[2 * pose + 1] = 0.0;
         if (COUNT) {
-            T->count_partial[pose] = s_cnt[0] + T->exact_count[pose];
-            if (T->tested_partial) T->tested_partial[pose] = s_tested[0];
+            T->count_partial[pose] = s_cnt[tid] + T->exact_count[pose];
+            if (T->tested_partial) T->tested_partial[pose] = s_tested[tid];
             if (T->exact_partial) T->exact_partial[pose] = T->exact_pairs[pose];
         }
     }
@@ -731,8 +717,9 @@ hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
     const size_t blocks = ((t.n_poses + kBmCullPoses - 1) / kBmCullPoses * (size_t)t.m.lig.n_tiles + kBmCullWaves - 1) / kBmCullWaves;
     if (blocks > 0x7fffffffULL || t.m.rec_n_tiles > 255) return hipErrorInvalidValue;
-    if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_cull<true>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), 0, stream, t);
-    else hipLaunchKernelGGL((dfire_bm_cull<false>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), 0, stream, t);
+    const size_t lds = (size_t)kBmCullWaves * kBmCullPoses * t.m.rec_n_tiles * sizeof(unsigned long long);
+    if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_cull<true>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
+    else hipLaunchKernelGGL((dfire_bm_cull<false>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
     return hipGetLastError();
 }
 
@@ -747,8 +734,13 @@ hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
 
 hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_gather<true>), dim3((unsigned)t.n_poses), dim3(512), 0, stream, t);
-    else hipLaunchKernelGGL((dfire_bm_gather<false>), dim3((unsigned)t.n_poses), dim3(512), 0, stream, t);
+    const int rows = t.m.lig.n_tiles * kBmJobRows;
+    int span = kBmJobRows;
+    while (span < rows && span < 512) span <<= 1;
+    const size_t per_wg = 512 / span;
+    const unsigned blocks = (unsigned)((t.n_poses + per_wg - 1) / per_wg);
+    if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_gather<true>), dim3(blocks), dim3(512), 0, stream, t);
+    else hipLaunchKernelGGL((dfire_bm_gather<false>), dim3(blocks), dim3(512), 0, stream, t);
     return hipGetLastError();
 }
 
