@@ -319,7 +319,7 @@ struct BmWaveShared {
     uint32_t queue[kBmQueue];                      // pairs for the exact path
 };
 struct BmShared {
-    unsigned char lut[2 * kBmLutBytes];   // [0]: blocks with a tracked atom (cells below the interface distance flagged), [1]: without
+    unsigned char lut[kBmLutBytes];   // indexed from the far end: cell' = floor(kBmCellMax + 1/2 - 64 d2), everything further reads cell' 0
     BmWaveShared w[kBmWaves];
 };
 
@@ -331,20 +331,23 @@ struct BmWaveCtx {
     size_t lo;       // first entry of the job
 };
 
-// Queue item: entry (local to the job) | (i * 8 + j) << 10 | b << 16
+// Queue item: entry (local to the job) | (i * 8 + j) << 10 | b << 16 | kBmFlagsOnly (the pair's table value is in the sum already:
+// only its interface flags are wanted)
+constexpr uint32_t kBmFlagsOnly = 1u << 19;
 template <bool COUNT>
 __device__ __noinline__ void bm_drain(BmArgs *T, const BmWaveCtx &W, const uint32_t *queue, uint32_t queued, int lane) {
     for (uint32_t k = (uint32_t)lane; k < queued; k += 64) {
         const uint32_t item = queue[k];
         const size_t e = W.lo + (item & 1023u);
-        const int i = (int)((item >> 13) & 7u), j = (int)((item >> 10) & 7u), b = (int)(item >> 16);
+        const int i = (int)((item >> 13) & 7u), j = (int)((item >> 10) & 7u), b = (int)((item >> 16) & 7u);
         const int la = W.ls * 8 + i, ra = W.RT * 64 + b * 8 + j;
         if (la >= T->m.lig.n_real || ra >= T->m.rec_n_real) continue;
         const size_t pose = T->ent_pose[W.tp * T->cap + e];
         const ExactCtx ex = bm_exact_ctx(T, pose);
         const Vec3 p = pose_ligand_atom(bm_ligand(T), 0, 0, T->poses + pose * T->stride, la);
         uint32_t cnt = 0;
-        const double v = exact_pair(ex, p, T->m.lig.tindex[la], la, ra, cnt);
+        const double v = exact_pair(ex, p, T->m.lig.tindex[la], la, ra, cnt);   // (sets the interface flags)
+        if (item & kBmFlagsOnly) continue;
         // order-free: 2^-40 fixed point (the one place where a table value is rounded: below the noise of any f64 sum order)
         const long long fix = __double2ll_rn(v * kBmFixScale);
         if (fix != 0) atomicAdd(reinterpret_cast<unsigned long long *>(T->exact_fix + pose), (unsigned long long)fix);
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
     const int n_rt = T->m.rec_n_tiles;
     {
         const uint8_t *lut = COUNT ? T->m.lut_full : T->m.lut;
-        for (int i = tid; i < 2 * kBmLutBytes / 16; i += kBmWaves * 64) reinterpret_cast<uint4 *>(S.lut)[i] = reinterpret_cast<const uint4 *>(lut)[i];
+        for (int i = tid; i < kBmLutBytes / 16; i += kBmWaves * 64) reinterpret_cast<uint4 *>(S.lut)[i] = reinterpret_cast<const uint4 *>(lut)[i];
     }
     BmWaveShared &WS = S.w[wave];
     if (lane < 4) reinterpret_cast<uint32_t *>(WS.cube + kBmCubeRows * kBmRowBytes)[lane] = 0u;   // the zero slot behind the last row
@@ -458,9 +461,10 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                         __builtin_amdgcn_global_load_lds((const global_u32 *)(rows + src_lig[t] + roff), (lds_u32 *)(WS.cube + t * 1024), 16, 0, 0);
                 }
             }
-            // which LUT: the offset rides in the seed of the distance sum (exact: integers far below 2^24)
-            const float lut_base = lig_tracked || __builtin_amdgcn_readlane((int)my_tracked, b) != 0 ? 0.f : (float)kBmLutBytes;
-            const float seed = 0.5f + lut_base, cell_max = kBmCellMax + lut_base;
+            // A block with an atom that has an interface-flag slot also queues its pairs closer than 2.5 A (bins 0 and 1,
+            // whose slots are the last two of a row) for the exact path, which sets the flags (src/dfire.rs:339-342).
+            const uint32_t flag_from = lig_tracked || __builtin_amdgcn_readlane((int)my_tracked, b) != 0 ? kBmNearCode : kBmFlagged;
+            constexpr float seed = kBmCellMax + 0.5f;
             // ---- the job's entries that hold block (a, b), in entry order
             uint32_t n_items = 0;
             for (int k = 0; k < n_chunks; k++) {
@@ -476,25 +480,27 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
             }
             // receptor subtile b of the tile: 4 pair records, wave-uniform, out of the registers loaded at the job's start
             // The block's distance arithmetic has its origin at the centre c of the receptor subtile's box:
-            //   D'' = |l - r|^2 + seed = (|r - c|^2 + seed) + |l - c|^2 - 2 (r - c) . (l - c)
+            //   E = seed - |l - r|^2 = (seed - |r - c|^2) - |l - c|^2 + 2 (r - c) . (l - c),     cell' = (u32)E
             // four packed operations per step instead of six (the differences need not be formed), all operands small
-            // enough (below 2^17 for every pair within reach of the cutoff) that the roundings stay inside eps.
+            // enough (below 2^17 for every pair within reach of the cutoff) that the roundings stay inside eps.  The LUT
+            // is indexed from the far end: a pair beyond its last cell has E < 0, which v_cvt_u32_f32 turns into cell' 0
+            // ("miss") like a NaN -- no clamp.
             auto lane_f32 = [](float v, int from) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), from)); };
             const float cbx = 0.5f * (lane_f32(my_box.lox, b) + lane_f32(my_box.hix, b));
             const float cby = 0.5f * (lane_f32(my_box.loy, b) + lane_f32(my_box.hiy, b));
             const float cbz = 0.5f * (lane_f32(my_box.loz, b) + lane_f32(my_box.hiz, b));
             const float rec_here = (b >> 1) == 0 ? recf[0] : (b >> 1) == 1 ? recf[1] : (b >> 1) == 2 ? recf[2] : recf[3];
-            v2f Rx[4], Ry[4], Rz[4], Rs[4];   // -2 (r - c), and |r - c|^2 + seed
+            v2f Rx[4], Ry[4], Rz[4], Rs[4];   // 2 (r - c), and seed - |r - c|^2
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int at = (b & 1) * 32 + q * 8;   // record q of the subtile: x0 x1 y0 y1 z0 z1 . .
                 const v2f x = v2f{lane_f32(rec_here, at), lane_f32(rec_here, at + 1)} - v2f{cbx, cbx};
                 const v2f y = v2f{lane_f32(rec_here, at + 2), lane_f32(rec_here, at + 3)} - v2f{cby, cby};
                 const v2f z = v2f{lane_f32(rec_here, at + 4), lane_f32(rec_here, at + 5)} - v2f{cbz, cbz};
-                Rs[q] = __builtin_elementwise_fma(x, x, __builtin_elementwise_fma(y, y, __builtin_elementwise_fma(z, z, v2f{seed, seed})));
-                Rx[q] = x * v2f{-2.f, -2.f};
-                Ry[q] = y * v2f{-2.f, -2.f};
-                Rz[q] = z * v2f{-2.f, -2.f};
+                Rs[q] = __builtin_elementwise_fma(-x, x, __builtin_elementwise_fma(-y, y, __builtin_elementwise_fma(-z, z, v2f{seed, seed})));
+                Rx[q] = x * v2f{2.f, 2.f};
+                Ry[q] = y * v2f{2.f, 2.f};
+                Rz[q] = z * v2f{2.f, 2.f};
             }
             // what a lane of a batch needs from memory, loaded one batch ahead
             struct BatchLoads {
@@ -551,11 +557,11 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
 #pragma unroll
                     for (int s8 = 0; s8 < 8; s8++) {
                         const int t = g * 8 + s8, q = t / kBmLig, i = t % kBmLig;
-                        v2f D = Rs[q] + v2f{l2[i], l2[i]};
+                        v2f D = Rs[q] - v2f{l2[i], l2[i]};
                         D = __builtin_elementwise_fma(Rz[q], v2f{lz[i], lz[i]}, D);
                         D = __builtin_elementwise_fma(Ry[q], v2f{ly[i], ly[i]}, D);
                         D = __builtin_elementwise_fma(Rx[q], v2f{lx[i], lx[i]}, D);
-                        const uint32_t c0 = bm_cvt_u32(fminf(D.x, cell_max)), c1 = bm_cvt_u32(fminf(D.y, cell_max));
+                        const uint32_t c0 = bm_cvt_u32(D.x), c1 = bm_cvt_u32(D.y);
                         w[2 * s8] = S.lut[c0];
                         w[2 * s8 + 1] = S.lut[c1];
                     }
@@ -578,13 +584,13 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                         wm = wm > m2 ? wm : m2;
                     }
                     asm volatile("" : "+v"(acc));   // the group's adds end here (the scheduler would park table values in registers)
-                    if (__builtin_expect(__ballot(wm >= kBmFlagged) != 0ull, 0)) {
+                    if (__builtin_expect(__ballot(wm >= flag_from) != 0ull, 0)) {
                         // pairs in flagged cells read 0.0 above; queue them for the exact path
                         uint32_t el_here = el;
                         asm volatile("" : "+v"(el_here));   // (keep the compiler from preparing any of this outside the branch)
 #pragma unroll
                         for (int k = 0; k < 16; k++) {
-                            const bool f = valid && w[k] >= kBmFlagged;
+                            const bool f = valid && w[k] >= flag_from;
                             const unsigned long long m = __ballot(f);
                             if (m == 0ull) continue;
                             if (queued > (uint32_t)kBmQueue - 64u) {   // room for 64 more, always: a pose's sum never depends on its batch
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                             }
                             const int t = g * 8 + (k >> 1), q = t / kBmLig, i = t % kBmLig;
                             const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            if (f) WS.queue[at] = el_here | (uint32_t)((la0 + i) * 8 + 2 * q + (k & 1)) << 10 | (uint32_t)b << 16;
+                            if (f) WS.queue[at] = el_here | (uint32_t)((la0 + i) * 8 + 2 * q + (k & 1)) << 10 | (uint32_t)b << 16 | (w[k] < kBmFlagged ? kBmFlagsOnly : 0u);
                             queued += (uint32_t)__popcll(m);
                         }
                     }

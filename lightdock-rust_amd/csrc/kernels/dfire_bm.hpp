@@ -41,7 +41,7 @@ constexpr double kBmKappa = 8.0;             // records hold fl32(kappa (x - c))
 constexpr int kBmCutCell = 900 * kBmCells;   // the cutoff 4 d2 = 900
 constexpr int kBmLutBytes = 14592;           // cells 0 .. 14591: everything beyond kBmCutCell + eps reads "miss"
 constexpr float kBmCellMax = 14591.0f;
-constexpr int kBmRowSlots = 22;              // slot 0 = 0.0 (miss), slot 1 + b = bin b (0..20; 20 = the read past the row at r = 15.0)
+constexpr int kBmRowSlots = 22;              // slot 0 = 0.0 (miss), slots 1..19 = bins 2..20 (20 = the read past the row at r = 15.0), slots 20, 21 = bins 0, 1
 constexpr int kBmRowBytes = kBmRowSlots * 8;
 constexpr int kBmLig = 8;                    // ligand atoms per job row: a job walks the blocks (kBmLig ligand atoms x 8 receptor atoms) of one
                                              // half of a ligand subtile -- half the table rows in LDS per wave, twice the waves per CU
@@ -55,6 +55,8 @@ constexpr int kBmHalves = LD_BM_HALVES;                 // a job walks 8 / kBmHa
 constexpr int kBmJobRows = kBmRows * kBmHalves;   // partial sums per entry
 constexpr int kBmCubeBytes = kBmCubeRows * kBmRowBytes + 16;  // + one zero slot behind the last row
 constexpr uint32_t kBmFlagged = kBmRowBytes;  // LUT code of a flagged cell: slot 0 of the NEXT row = 0.0, above every bin code
+constexpr uint32_t kBmNearCode = 20 * 8;      // codes of bins 0 and 1 (r < 2.5 A, the only pairs that can set interface flags) start here
+__host__ __device__ inline uint32_t bm_slot_of_bin(uint32_t bin) { return bin >= 2 ? bin - 1 : 20 + bin; }
 constexpr int kBmTypes = 170;                // 169 DFIRE types + one all-zero type for padding atoms
 constexpr int kBmWaves = kBmLig == 4 ? 12 : 8;  // waves per dfire_bm_pairs workgroup (one workgroup per CU: what its LDS holds)
 constexpr int kBmPartEntries = 1024;         // entries of a tile pair in one job
@@ -78,7 +80,7 @@ struct BmModel {
     const uint32_t *lig_rowbase = nullptr;      // [n_tiles*64]: byte offset of the atom's type block in `rows`
     // tables
     const double *rows = nullptr;               // [kBmTypes lig][kBmTypes rec][kBmRowSlots]
-    const uint8_t *lut = nullptr;               // 2 x kBmLutBytes codes: for blocks with / without an atom that has an interface-flag slot
+    const uint8_t *lut = nullptr;               // kBmLutBytes codes, cell' = floor(kBmCellMax + 1/2 - 64 d2)
     const uint8_t *rec_sub_tracked = nullptr;   // [rec subtiles]: 1 = holds an atom with a flag slot
     const uint8_t *lig_sub_tracked = nullptr;   // [lig subtiles]
     const uint8_t *lut_full = nullptr;          // the same without elided zero bins (counting launches)

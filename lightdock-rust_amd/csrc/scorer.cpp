@@ -657,20 +657,24 @@ double dfire_bm_error_bound(double ubound, double lig_extent) {
     return 2.0 * eps;  // twice the bound, LUT cells
 }
 
-// Cell k holds the pairs with D'' = 64 d2 + 1/2 (f32) in [k, k + 1), i.e. a true 4 d2 within
-// ((k - 1/2 - eps) / 16, (k + 1/2 + eps) / 16).  A cell with ONE answer for that whole interval carries the bin's slot
-// in the block's table rows ((bin + 1) * 8; 0 = "miss" beyond the cutoff or a bin that is zero for the whole complex);
-// any other cell -- a bin step, the interface distance or the cutoff inside, or all of it below the interface distance
-// (src/dfire.rs:339: flags to set) -- is flagged: the kernel reads 0.0 and recomputes the pair in f64.
-std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins, bool sets_flags) {
+// The kernel computes E = kBmCellMax + 1/2 - 64 d2 (f32) and reads cell' = floor(E), everything further than the LUT
+// reaches (E < 0) reading cell' 0.  Cell' k' = kBmCellMax - k holds the pairs with 64 d2 within (k - 1/2 - eps, k + 1/2 + eps),
+// i.e. a true 4 d2 within ((k - 1/2 - eps) / 16, (k + 1/2 + eps) / 16).  A cell with ONE answer for that whole interval
+// carries the bin's slot in the block's table rows (bm_slot_of_bin(bin) * 8; 0 = "miss" beyond the cutoff or a bin that is
+// zero for the whole complex); a cell with a bin step or the cutoff inside is flagged: the kernel reads 0.0 and recomputes
+// the pair in f64.  The interface distance (src/dfire.rs:339) lies inside bin 1: the kernel sends the pairs of bins 0 and 1
+// of a block that has an atom with a flag slot to the exact path as well, for their flags only.
+std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins) {
     const DfireBinning b = build_dfire_binning();
     const double iface_scaled = 4.0 * dfire_interface_d2();
+    if (!(iface_scaled < 4.0 * b.step[2] && iface_scaled >= 4.0 * b.step[1]))
+        throw Error(LD_ERR_INVALID, "DFIRE block-major LUT: the interface distance is not inside bin 1");
     std::vector<uint8_t> codes(kBmLutBytes, 0);
     for (int k = 0; k < kBmLutBytes; k++) {
+        uint8_t &code = codes[kBmLutBytes - 1 - k];
         const double ilo = (k - 0.5 - eps_cells) / kBmCells, ihi = (k + 0.5 + eps_cells) / kBmCells;
         if (ilo > 900.0) continue;  // beyond the cutoff for sure
-        // (a block none of whose atoms has an interface-flag slot has no flag to set: its clashing pairs are ordinary pairs)
-        bool flagged = ihi >= 900.0 || (sets_flags && ilo <= iface_scaled);
+        bool flagged = ihi >= 900.0;
         int base_bin = 0;
         for (int s = 1; s <= 20; s++) {
             const double at = 4.0 * b.step[s];
@@ -678,14 +682,15 @@ std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins, bool set
             else if (at <= ihi) flagged = true;
         }
         if (flagged) {
-            codes[k] = (uint8_t)kBmFlagged;
+            code = (uint8_t)kBmFlagged;
             continue;
         }
         if (dfire_bin_reference(std::max(ilo, 0.0) / 4.0) != base_bin || dfire_bin_reference(ihi / 4.0) != base_bin)
             throw Error(LD_ERR_INVALID, "DFIRE block-major LUT self-check failed in cell " + std::to_string(k));
-        codes[k] = (zero_bins >> base_bin) & 1u ? 0 : (uint8_t)((base_bin + 1) * 8);
+        // (bins 0 and 1 are never elided: a block with tracked atoms recognises its flag-setting pairs by their codes)
+        code = base_bin >= 2 && ((zero_bins >> base_bin) & 1u) ? 0 : (uint8_t)(bm_slot_of_bin((uint32_t)base_bin) * 8);
     }
-    if (codes[kBmLutBytes - 1] != 0) throw Error(LD_ERR_INVALID, "DFIRE block-major LUT: the clamp cell is not a miss");
+    if (codes[0] != 0) throw Error(LD_ERR_INVALID, "DFIRE block-major LUT: the far cell is not a miss");
     return codes;
 }
 
@@ -746,13 +751,8 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
         for (double &v : step4) v *= 4.0;
         M.bin_step = arena_.upload(step4);
     }
-    auto two_luts = [&](uint32_t zero_bins) {   // [0]: blocks with a tracked atom, [1]: blocks without
-        std::vector<uint8_t> both = build_bm_lut(eps, zero_bins, true), plain = build_bm_lut(eps, zero_bins, false);
-        both.insert(both.end(), plain.begin(), plain.end());
-        return both;
-    };
-    M.lut = arena_.upload(two_luts(packed_zero_bins_));
-    M.lut_full = packed_zero_bins_ ? arena_.upload(two_luts(0)) : M.lut;  // counting launches count every pair
+    M.lut = arena_.upload(build_bm_lut(eps, packed_zero_bins_));
+    M.lut_full = packed_zero_bins_ ? arena_.upload(build_bm_lut(eps, 0)) : M.lut;  // counting launches count every pair
     {   // subtiles that hold an atom with an interface-flag slot (restraint atoms, membrane beads)
         auto tracked = [](const TiledSoA &m) {
             std::vector<uint8_t> t(m.hslot.size() / 8, 0);
@@ -803,13 +803,13 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
         }
         M.lig_local = arena_.upload(local);
     }
-    {   // rows[l][r][0] = 0.0; rows[l][r][1 + b] = potential[r * 3380 + l * 20 + b], b = 0..20 (20 = the read past the row, src/dfire.rs:338)
+    {   // rows[l][r][0] = 0.0; rows[l][r][bm_slot_of_bin(b)] = potential[r * 3380 + l * 20 + b], b = 0..20 (20 = the read past the row, src/dfire.rs:338)
         std::vector<double> rows((size_t)kBmTypes * kBmTypes * kBmRowSlots, 0.0);
         for (uint32_t l = 0; l < 169; l++)
             for (uint32_t r = 0; r < 169; r++)
                 for (uint32_t b = 0; b <= 20; b++) {
                     const size_t at = (size_t)r * kDfireRowStride + l * 20 + b;
-                    if (at < LD_DFIRE_TABLE_LEN) rows[((size_t)l * kBmTypes + r) * kBmRowSlots + 1 + b] = desc.potential[at];
+                    if (at < LD_DFIRE_TABLE_LEN) rows[((size_t)l * kBmTypes + r) * kBmRowSlots + bm_slot_of_bin(b)] = desc.potential[at];
                 }
         M.rows = arena_.upload(rows);
     }

@@ -65,7 +65,7 @@ struct DfireBinning {
 DfireBinning build_dfire_binning();                  // throws if the self-check fails
 double dfire_interface_d2();                         // largest d2 with sqrt(d2)*2-1 <= 3.9
 std::vector<uint32_t> build_packed_lut(int cells_per_unit, double eps, uint32_t zero_bins = 0);  // kPackedLutCells * cells_per_unit words
-std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins = 0, bool sets_flags = true);  // kBmLutBytes codes of the block-major kernel (kernels/dfire_bm.hpp)
+std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins = 0);  // kBmLutBytes codes of the block-major kernel (kernels/dfire_bm.hpp)
 
 class Scorer {
    public:
