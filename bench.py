@@ -138,15 +138,67 @@ def cpu_baseline(case, table, poses, budget_s, threads):
                       "no SIMD intrinsics" % (n, threads, dt, n1)}, out
 
 
-def profile_entry(workload, batch, kernel):
+KERNEL_SOURCES = ("lightdock-rust_amd/csrc/kernels/dfire_bm.hip", "lightdock-rust_amd/csrc/kernels/dfire_bm.hpp",
+                  "lightdock-rust_amd/csrc/kernels/dfire_device.hpp", "lightdock-rust_amd/csrc/kernels/dfire_packed.hip",
+                  "lightdock-rust_amd/csrc/kernels/dfire_packed.hpp", "lightdock-rust_amd/csrc/kernels/dfire_tiled.hip",
+                  "lightdock-rust_amd/csrc/kernels/dfire_tiled.hpp", "lightdock-rust_amd/csrc/kernels/pose_energy.hip",
+                  "lightdock-rust_amd/csrc/kernels/pose_energy.hpp", "lightdock-rust_amd/csrc/kernels/gso_step.hip",
+                  "lightdock-rust_amd/csrc/scorer.cpp")
+
+
+def kernel_source_hash():
+    """What ties a committed counter profile to the build it was taken from: a hash of the kernel sources and of
+    scorer.cpp (launch shapes, LUTs, layouts).  tools/update_traffic.py stamps it on every entry of profiles/traffic.json."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        h.update(rel.encode())
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_entry(workload, units, kernel, flags=""):
     """Per-launch counter values of the pair kernel from the rocprofv3 PMC passes committed under
     profiles/ (collected in separate --pmc runs of this same command; profiles/README.md gives the
-    unit and gfx950 corrections).  {} when no profile matches workload, batch and kernel."""
+    unit and gfx950 corrections).  Returns (entry, stale): {} when no profile matches workload, units per launch,
+    flags and kernel; stale = the entry was taken from another build of the kernels (its counters are NOT reported)."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except (OSError, ValueError):
-        return {}
-    return t.get("%s:%d:%s" % (workload, batch, kernel), {})
+        return {}, False
+    e = t.get("%s:%d:%s%s" % (workload, units, kernel, flags), {})
+    if e and e.get("source_hash") != kernel_source_hash():
+        return {}, True
+    return e, False
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the layout
+    torch.distributed.run gives), BEFORE anything initialises a GPU in this process.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    forced = os.environ.get("LD_BENCH_FORCE_DEVICE")
+    if forced is None and "--backend" in argv and argv[argv.index("--backend") + 1] == "gloo" and os.environ.get("LD_BENCH_NO_GPU_CHECK"):
+        visible = n                                   # CPU dry run of the launcher (tests/test_multi_cpu.py)
+    else:
+        import torch                                  # counting devices does not initialise the GPU
+        visible = torch.cuda.device_count()
+    if forced is None and n > visible:
+        raise SystemExit("--gpus %d but %d device(s) visible (set LD_BENCH_FORCE_DEVICE=<id> for a dry run of the N-rank path on one GPU)" % (n, visible))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    codes = [p.wait() for p in procs]
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit("rank(s) failed: %s" % ", ".join("%d (exit %d)" % rc for rc in bad))
+    raise SystemExit(0)
 
 
 def main():
@@ -164,19 +216,18 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     args = ap.parse_args()
     system, kind, default_size = WORKLOADS[args.workload]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])          # does not return
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("LD_BENCH_FORCE_DEVICE") is not None:      # dry runs of the N > 1 path on a 1-GPU box
-        local = int(os.environ["LD_BENCH_FORCE_DEVICE"])
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the pose-energy path has no CPU fallback")
-    if local >= torch.cuda.device_count():      # ranks that each see only their own GPU (HIP_VISIBLE_DEVICES per rank)
-        local = local % max(1, torch.cuda.device_count())
+    local = ge.package().multi.device_of_rank(local, torch.cuda.device_count(), os.environ.get("LD_BENCH_FORCE_DEVICE"))
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -315,7 +366,18 @@ def main():
     if rank == 0:
         kern_s = kern_ms / 1e3 / max(launches, 1)
         achieved = algo_bytes_launch / kern_s / 1e9
-        prof = profile_entry(args.workload, int(units_per_launch) if kind == "k1" else 0, info["pair_kernel_name"])
+        flags = "" if not args.zero_last_bin else ":zero-last-bin"
+        prof, stale = profile_entry(args.workload, int(units_per_launch) if kind == "k1" else len(mine), info["pair_kernel_name"], flags)
+        # The vector units issue most of what these kernels run (packed f32, f64, conversions, integer max) at one wave
+        # instruction per ~4.5 cycles per SIMD (profiles/r02_valu_issue_rates.txt); only plain f32 add / mul / fma and
+        # bitwise operations go faster.  The instruction-count floor of a launch is what that rate allows.
+        binding = None
+        if prof.get("valu_insts_per_launch"):
+            floor_ms = 1e3 * prof["valu_insts_per_launch"] * 4.5 / (1024 * 2.4e9)
+            binding = {"what": prof.get("binding", "valu-issue"), "valu_floor_ms": floor_ms, "frac_of_kernel_time": floor_ms / (1e3 * kern_s),
+                       "how": "SQ_INSTS_VALU x 4.5 cycles / (1024 SIMDs x 2.4 GHz)"}
+            if prof.get("vmem_insts_per_launch"):
+                binding["tcp_floor_ms"] = 1e3 * prof["vmem_insts_per_launch"] * 17 / (256 * 2.4e9)
         compute = None
         if prof.get("valu_insts_per_launch"):
             lane_ops = 64.0 * prof["valu_insts_per_launch"] / kern_s
@@ -347,7 +409,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "note": "algorithmic bytes (SURVEY 8d) over kernel time; the working set is L2 resident, so measured HBM "
                                  "traffic (`traffic`) is far below it and the binding limits are on chip -- see `l2`, `l1`, `compute`",
-                         "compute": compute, "l1": l1, "l2": l2,
+                         "profile_stale": stale, "binding": binding, "compute": compute, "l1": l1, "l2": l2,
                          "nominal_pair_tests_per_s": info["pair_tests_per_pose"] * units_per_launch / kern_s,
                          "evaluated_pair_tests_per_s": (64.0 * blocks * units_per_launch / kern_s) if blocks else None},
         }

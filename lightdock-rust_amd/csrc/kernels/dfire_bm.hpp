@@ -43,6 +43,9 @@ constexpr int kBmLutBytes = 14592;           // cells 0 .. 14591: everything bey
 constexpr float kBmCellMax = 14591.0f;
 constexpr int kBmRowSlots = 22;              // slot 0 = 0.0 (miss), slots 1..19 = bins 2..20 (20 = the read past the row at r = 15.0), slots 20, 21 = bins 0, 1
 constexpr int kBmRowBytes = kBmRowSlots * 8;
+#ifndef LD_BM_WAVES
+#define LD_BM_WAVES 8
+#endif
 constexpr int kBmLig = 8;                    // ligand atoms per job row: a job walks the blocks (kBmLig ligand atoms x 8 receptor atoms) of one
                                              // half of a ligand subtile -- half the table rows in LDS per wave, twice the waves per CU
 constexpr int kBmSplit = 8 / kBmLig;         // job rows per ligand subtile
@@ -58,7 +61,7 @@ constexpr uint32_t kBmFlagged = kBmRowBytes;  // LUT code of a flagged cell: slo
 constexpr uint32_t kBmNearCode = 20 * 8;      // codes of bins 0 and 1 (r < 2.5 A, the only pairs that can set interface flags) start here
 __host__ __device__ inline uint32_t bm_slot_of_bin(uint32_t bin) { return bin >= 2 ? bin - 1 : 20 + bin; }
 constexpr int kBmTypes = 170;                // 169 DFIRE types + one all-zero type for padding atoms
-constexpr int kBmWaves = kBmLig == 4 ? 12 : 8;  // waves per dfire_bm_pairs workgroup (one workgroup per CU: what its LDS holds)
+constexpr int kBmWaves = kBmLig == 4 ? 12 : LD_BM_WAVES;  // waves per dfire_bm_pairs workgroup (one workgroup per CU: what its LDS holds)
 constexpr int kBmPartEntries = 1024;         // entries of a tile pair in one job
 constexpr int kBmQueue = 128;                // per wave: pairs waiting for the exact path
 constexpr double kBmFixScale = 1099511627776.0;  // 2^40: fixed-point units of the exact path's sum

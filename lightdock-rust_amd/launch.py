@@ -64,11 +64,8 @@ def main(argv=None):
     pkg = ge.package()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
-    if os.environ.get("LIGHTDOCK_DEVICE") is not None:      # e.g. several ranks on one GPU for a dry run
-        local = int(os.environ["LIGHTDOCK_DEVICE"])
-    n_dev = pkg.device_count()
-    if n_dev > 0 and local >= n_dev:       # ranks that each see only their own GPU (HIP_VISIBLE_DEVICES per rank)
-        local = local % n_dev
+    # one process per GPU; LIGHTDOCK_DEVICE pins every rank to one device (several ranks on one GPU for a dry run)
+    local = pkg.multi.device_of_rank(local, pkg.device_count(), os.environ.get("LIGHTDOCK_DEVICE"))
     pkg.init(local)
     setup = json.load(open(args.setup))
     sim = os.path.dirname(os.path.abspath(args.setup))

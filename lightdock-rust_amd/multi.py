@@ -19,6 +19,32 @@ def world(dist):
     return dist.get_rank(), dist.get_world_size()
 
 
+def device_of_rank(local_rank, visible_devices, forced=None):
+    """The device a rank computes on.  One process per GPU: local rank r takes device r; a rank that sees only its own
+    GPU (per-rank HIP_VISIBLE_DEVICES) takes device 0; `forced` (LD_BENCH_FORCE_DEVICE / LIGHTDOCK_FORCE_DEVICE) pins every rank to
+    one device for dry runs of the N-rank path on a 1-GPU box.  More ranks than devices without `forced` is an error:
+    silently sharing a GPU would report 1-GPU numbers as an N-GPU curve."""
+    if forced is not None and str(forced) != "":
+        d = int(forced)
+        if not 0 <= d < max(1, visible_devices):
+            raise ValueError("forced device %d but %d visible" % (d, visible_devices))
+        return d
+    if visible_devices <= 0:
+        raise ValueError("no device visible")
+    if visible_devices == 1:
+        if local_rank > 0 and not _own_visible_device():
+            raise ValueError("local rank %d but one device visible and no per-rank HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES" % local_rank)
+        return 0
+    if local_rank >= visible_devices:
+        raise ValueError("local rank %d but %d devices visible" % (local_rank, visible_devices))
+    return local_rank
+
+
+def _own_visible_device():
+    import os
+    return any(os.environ.get(k) not in (None, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+
+
 def shard(n_items, rank, world_size):
     """Indices owned by `rank`: strided, so every rank gets floor or ceil of n/W items."""
     return list(range(rank, n_items, world_size))

@@ -971,3 +971,26 @@ def test_receptor_larger_than_one_ballot(pkg, orc, table, tmp_path):
     finally:
         os.environ.pop("LIGHTDOCK_DFIRE_KERNEL")
     assert rel_err(ap.energy_batch(poses), want) < REL_TOL
+
+
+def test_bench_plain_command_runs_n_ranks(pkg):
+    """`python bench.py --gpus 2` (no torchrun): bench.py starts the two ranks itself; on this 1-GPU box both are pinned to
+    device 0 (LD_BENCH_FORCE_DEVICE) and the timing collectives go over gloo.  One JSON line, n_gpus 2, whole-job value."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LD_BENCH_FORCE_DEVICE="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([os.sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "gso-1ppe",
+                        "--swarms", "8", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["swarms_this_rank"] == 4
+    # without the override the same command must refuse rather than share one GPU silently
+    env.pop("LD_BENCH_FORCE_DEVICE")
+    r = subprocess.run([os.sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    if pkg.device_count() < 2:
+        assert r.returncode != 0 and "device(s) visible" in r.stderr

@@ -85,3 +85,47 @@ def test_gather_detects_missing_and_duplicate_swarms(pkg):
     with pytest.raises(RuntimeError, match="not evaluated"):
         multi.gather_by_swarm({0: "a"}, 2, None)
     assert multi.gather_by_swarm({1: "b", 0: "a"}, 2, None) == ["a", "b"]
+
+
+def test_rank_to_device_mapping(pkg, monkeypatch):
+    """bench.py and launch.py map ranks to devices through one function: one process per GPU, a rank that sees only
+    its own GPU takes device 0, a forced device pins all ranks (dry runs), and more ranks than devices without that
+    is an error -- never N ranks silently sharing one GPU."""
+    from lightdock_rust_amd import multi
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    assert [multi.device_of_rank(r, 8) for r in range(8)] == list(range(8))
+    assert multi.device_of_rank(0, 1) == 0
+    with pytest.raises(ValueError):
+        multi.device_of_rank(1, 1)                       # two ranks, one visible device, nothing says it is the rank's own
+    with pytest.raises(ValueError):
+        multi.device_of_rank(8, 8)
+    with pytest.raises(ValueError):
+        multi.device_of_rank(0, 0)
+    assert [multi.device_of_rank(r, 1, forced="0") for r in range(4)] == [0, 0, 0, 0]
+    assert multi.device_of_rank(3, 8, forced="5") == 5
+    with pytest.raises(ValueError):
+        multi.device_of_rank(0, 2, forced="2")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3")        # per-rank visibility: the one device it sees is its own
+    assert multi.device_of_rank(3, 1) == 0
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (the driver's scaling run would otherwise
+    report 1-GPU numbers at every N).  Here (no GPU): the parent refuses N > visible devices; past that check both
+    children start with the torchrun environment and stop at "needs an MI355X", and the parent reports the failure."""
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("LD_BENCH_FORCE_DEVICE", None)
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "device(s) visible" in r.stderr
+    env["LD_BENCH_NO_GPU_CHECK"] = "1"
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("needs an MI355X") == 2           # both ranks ran
+    assert "rank(s) failed: 0 (exit 1), 1 (exit 1)" in r.stderr
+    assert r.stdout.strip() == ""                            # and no JSON line pretends otherwise
