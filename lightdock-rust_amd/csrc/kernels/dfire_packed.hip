@@ -25,14 +25,6 @@
 
 #include "dfire_device.hpp"
 
-#ifdef LD_PACKED_STAMPS
-// diagnostic build (tools/build_variant.sh stamps -DLD_PACKED_STAMPS): s_memtime stamps summed over all waves
-__device__ unsigned long long g_ld_stamps[8];
-extern "C" int ld_debug_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ld_stamps), 64); }
-#define LD_STAMP(...) __VA_ARGS__
-#else
-#define LD_STAMP(...)
-#endif
 namespace ld {
 
 namespace {
@@ -178,7 +170,6 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
     // pairs for the exact path: ligand atom of the tile | receptor atom << 6
     __shared__ uint32_t s_queue[kPackedWaves][kPackedQueue];
 
-    LD_STAMP(const unsigned long long ts0 = __builtin_amdgcn_s_memtime(); unsigned long long t_setup = 0, t_tile = 0, t_loop = 0, n_tiles = 0, n_trips = 0, td0 = 0, td1 = 0;)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -258,7 +249,6 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
 
         const __amdgpu_buffer_rsrc_t table = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<double *>(T.table), 0, (int)(kTiledTableDoubles * sizeof(double)), 0x00020000);
-        LD_STAMP(t_setup = __builtin_amdgcn_s_memtime() - ts0;)
         // ---- 2. receptor tiles, 64 per ballot; `tile_body(RT, tracked atoms of RT)` for every surviving
         // tile of this wave's share
         auto for_each_tile = [&](auto &&tile_body) {
@@ -286,7 +276,6 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
 
         // ---- 3. stream the surviving tiles through the LDS slice
         for_each_tile([&](const int RT, const unsigned long long rec_tracked) {
-                LD_STAMP(td0 = __builtin_amdgcn_s_memtime();)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // reads of the previous tile are done
                 const unsigned char *gsrc = reinterpret_cast<const unsigned char *>(rec_pairs + (size_t)RT * 32) + lane * 16;
                 __builtin_amdgcn_global_load_lds((const global_u32 *)gsrc, (lds_u32 *)rect, 16, 0, 0);
@@ -295,7 +284,6 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
                 unsigned long long smask = __ballot(sub_near);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA has landed
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                LD_STAMP(td1 = __builtin_amdgcn_s_memtime(); t_tile += td1 - td0; n_tiles++;)
                 if (COUNT) tested += (uint32_t)__popcll(smask);
 
                 // ---- 4. surviving blocks, two per trip ---------------------------------------------
@@ -303,7 +291,6 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
                 // of the wave takes the first block left, the upper half the second; an odd block
                 // left over is paired with the far-away records behind the tile (all misses).
                 while (smask) {
-                    LD_STAMP(n_trips++;)
                     // bit k of smask = block (ligand subtile k >> 3, receptor subtile k & 7); 64 = the far-away
                     // ligand subtile x receptor subtile 0.  Each half of the wave picks its block out of the
                     // scalar pair with one 64-bit shift.
@@ -329,7 +316,6 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
                     const uint32_t w0 = s_lut[c0], w1 = s_lut[c1];
                     uint32_t off0 = Lt + __float_as_uint(Rb.z) + w0;  // src/dfire.rs:338, re-laid out
                     uint32_t off1 = Lt + __float_as_uint(Rb.w) + w1;
-#ifndef LD_PACKED_NO_SLOW  // (diagnostic builds, tools/build_variant.sh)
                     // flagged cell or an atom outside the f32 frame: bit 30 (or 31) of the sum
                     // (branches on ballots: every lane goes along, `queued` stays wave-uniform)
                     if (__builtin_expect(__ballot((off0 > off1 ? off0 : off1) >= kPackedSlow) != 0ull, 0)) {
@@ -351,7 +337,7 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
                             // has an interface-flag slot
                             if (__ballot(tag0 == lean_flags || tag1 == lean_flags) != 0ull) {
                                 const uint32_t la_bit = lsub * 8u + (uint32_t)pi, ra_bit = rsub * 8u + 2u * (uint32_t)pq;
-                                const bool lt = (lig_tracked >> la_bit) & 1ull;
+                                const bool lt = (lig_tracked >> (la_bit & 63u)) & 1ull;   // (the far-away partner of an odd block has lsub = 8: only misses)
                                 const bool t0 = lt || ((rec_tracked >> (ra_bit & 63u)) & 1ull), t1 = lt || ((rec_tracked >> ((ra_bit + 1) & 63u)) & 1ull);
                                 lean0 = lean0 || (tag0 == lean_flags && !t0 && clear0);
                                 lean1 = lean1 || (tag1 == lean_flags && !t1 && clear1);
@@ -364,7 +350,6 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
                             off0 = lean0 ? f0 : off0;
                             off1 = lean1 ? f1 : off1;
                         }
-#ifndef LD_PACKED_NO_FULL
                         if (__builtin_expect(__ballot(need0 || need1) != 0ull, 0)) {
                             // queue them for the exact path (after the loops) and read misses for now
                             const bool real_block = lsub < 8u;  // not the far-away partner of an odd block
@@ -381,23 +366,16 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
                             off0 = need0 ? kPackedMiss : off0;
                             off1 = need1 ? kPackedMiss : off1;
                         }
-#endif
                     }
-#endif
                     // retire the previous trip's gathers only now (their L2 latency hides behind
                     // this trip's LDS reads and arithmetic), then issue this trip's
                     acc += pend0;
                     acc += pend1;
                     asm volatile("" : "+v"(acc) : : "memory");
-#ifndef LD_PACKED_NO_GATHER
                     pend0 = table_entry(table, off0);
                     pend1 = table_entry(table, off1);
-#else
-                    pend0 = (double)off0; pend1 = (double)off1;
-#endif
                     if (COUNT) cnt += (off0 < kPackedMiss && !beyond_cutoff_slot(off0) ? 1u : 0u) + (off1 < kPackedMiss && !beyond_cutoff_slot(off1) ? 1u : 0u);
                 }
-                LD_STAMP(t_loop += __builtin_amdgcn_s_memtime() - td1;)
         });
 
         // ---- 4b. the pairs the f32 test could not decide, in f64 --------------------------------------
@@ -447,15 +425,6 @@ __global__ __launch_bounds__(kPackedWaves * 64, LD_PACKED_WAVES_PER_SIMD) void d
     }
 
     // ---- 5. reduction ----------------------------------------------------------------------------
-    LD_STAMP(if (lane == 0) {
-        atomicAdd(&g_ld_stamps[0], __builtin_amdgcn_s_memtime() - ts0);
-        atomicAdd(&g_ld_stamps[1], t_setup);
-        atomicAdd(&g_ld_stamps[2], t_tile);
-        atomicAdd(&g_ld_stamps[3], t_loop);
-        atomicAdd(&g_ld_stamps[4], n_tiles);
-        atomicAdd(&g_ld_stamps[5], 1ull);
-        atomicAdd(&g_ld_stamps[6], n_trips);
-    })
     acc += pend0;
     acc += pend1;
     acc = wave_sum(acc);

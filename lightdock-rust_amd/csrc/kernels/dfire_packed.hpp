@@ -4,23 +4,25 @@
 // subtile boxes), but the pair test runs in packed f32 on 16-byte records and only the pairs whose
 // f32 distance cannot decide the reference's f64 result are recomputed in f64:
 //
-//   record coordinate  u = fl32(2 (x - c))          c = centre of the receptor's box
-//   D' = fl32(sum (u_rec - u_lig)^2 + 1/2)          = 4 d2 + 1/2 up to eps (dfire_f32_error_bound)
-//   cell = min((unsigned)D', 1024)
+//   record coordinate  u = fl32(kappa (x - c))      c = centre of the receptor's box, kappa = 2 sqrt(SC)
+//   D' = fl32(sum (u_rec - u_lig)^2 + 1/2)          = SC * 4 d2 + 1/2 up to eps (dfire_f32_error_bound)
+//   cell = min((unsigned)D', 1024 SC)               SC = LUT cells per unit of 4 d2: 1 by default, 2 with LIGHTDOCK_PACKED_CELLS=2
 //
 // Everything the reference derives from d2 -- the cutoff d2 <= 225 (src/dfire.rs:334), the distance
 // bin (:336-337) and the interface test d <= 3.9 (:339) -- is a step function of 4 d2 with steps at
 // the squares (k+1)^2, at 4*iface_d2 and at 900.  The half added to D' puts those integer steps in
 // the middle of a cell, so a cell holds at most one of them.  A cell whose whole interval
-// [cell - 1/2 - eps, cell + 1/2 + eps) lies between two steps has ONE answer for every f64 distance
-// that can produce it: the LUT word is the table term of that bin (or kTiledLutMiss beyond the
-// cutoff).  The other cells (about 3 % of the in-cutoff pairs) are flagged kTiledLutSlow: there the
-// kernel compares the f32 D with the step and, only if it is within eps of it, recomputes the pair
+// [(cell - 1/2) / SC - eps, (cell + 1/2) / SC + eps) lies between two steps has ONE answer for every f64 distance
+// that can produce it: the LUT word is the table term of that bin (or kPackedMiss beyond the
+// cutoff).  The other cells (2.6 % of the in-cutoff pairs with unit cells, half that with half-unit cells) are flagged
+// kPackedSlow: there the kernel compares the f32 D with the step and, only if it is within eps of it (5.1e-3 units of 4 d2
+// for a 256-unit frame with unit cells, 3.5e-3 with half-unit cells), recomputes the pair
 // in f64 from the f64 coordinates (receptor image in HBM/L2, ligand atom re-posed), in the
 // reference's operation order.  Bins, cutoff and interface flags are therefore the reference's f64
 // results bit for bit, and the f64 `+=` of table values is untouched.
 // Atoms further than `ubound` from c in the scaled frame (absurd ANM extents, ligand poses far from
-// the receptor) carry NaN coordinates: D' = NaN converts to cell 0, which is always on the exact path.
+// the receptor) carry kPackedSlow in their type term: every pair of theirs sums to a flagged offset and goes
+// through the exact path (a NaN distance converts to cell 1024 SC, beyond the cutoff).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -37,17 +39,8 @@ namespace ld {
 // once; the price is a cell LUT per wave, which is why the default LUT has one cell per unit then
 // (6.6 KiB of LDS per wave, 6 waves per SIMD).  Measured against 4 (MI355X, same box): 1k4c +2.3..4.5 %,
 // GSO 1k4c +4.5 %, GSO 1ppe +1.7 %, 1ppe equal.
-#ifndef LD_PACKED_WAVES
-#define LD_PACKED_WAVES 1
-#endif
-constexpr int kPackedWaves = LD_PACKED_WAVES;
-// LD_PACKED_FREE_WAVES: the waves of a workgroup share the LUT but nothing else -- no closing barrier,
-// one partial per wave
-#ifdef LD_PACKED_FREE_WAVES
-constexpr int kPackedPartialsPerGroup = kPackedWaves;
-#else
+constexpr int kPackedWaves = 1;
 constexpr int kPackedPartialsPerGroup = 1;
-#endif
 constexpr int kPackedLutCells = 1028;    // per cell of 4 d2: cells 0..1024 (1024 = everything further), padded to 16 bytes
 constexpr float kPackedCellMax = 1024.0f;
 constexpr int kPackedQueue = 64;         // per wave: pairs waiting for the exact f64 path

@@ -31,14 +31,6 @@
 
 #include <cmath>
 
-#ifdef LD_TILED_STAMPS
-// diagnostic build (tools/build_stamps_variant.sh): s_memtime stamps summed over all waves, read by tools/stamps_experiment.py
-__device__ unsigned long long g_ld_stamps[8];
-extern "C" int ld_debug_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ld_stamps), 64); }
-#define LD_STAMP(...) __VA_ARGS__
-#else
-#define LD_STAMP(...)
-#endif
 namespace ld {
 
 namespace {
@@ -228,7 +220,6 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
     // 3616 + 192 + 4 x 4096 = 20 192 bytes for 4 waves: 8 workgroups (32 waves) per CU.  The
     // per-wave results of the final reduction reuse the first 16 bytes of each wave's own slice.
 
-    LD_STAMP(const unsigned long long ts0 = __builtin_amdgcn_s_memtime(); unsigned long long t_setup = 0, t_dma = 0, t_loop = 0, t_n = 0; unsigned long long td0 = 0, td1 = 0;)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -325,7 +316,6 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
         const __amdgpu_buffer_rsrc_t table = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<double *>(T.table), 0, (int)(kTiledTableDoubles * sizeof(double)), 0x00020000);
 
-        LD_STAMP(t_setup = __builtin_amdgcn_s_memtime() - ts0;)
         // ---- 2. receptor tiles, 64 per ballot ---------------------------------------------------
         for (int base = 0; base < T.rec.n_tiles; base += 64) {
             bool tile_near = false;
@@ -341,7 +331,6 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
                 if (turn++ % T.split != part) continue;
                 // 2 KiB of records straight from L2/HBM into this wave's LDS slice (LDS-DMA: no
                 // VGPRs, no ds_write); lane l moves bytes [16 l, 16 l + 16) of each KiB
-                LD_STAMP(td0 = __builtin_amdgcn_s_memtime();)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // reads of the previous tile are done
                 const unsigned char *gsrc = reinterpret_cast<const unsigned char *>(rec_atoms + (size_t)RT * 64) + lane * 16;
                 __builtin_amdgcn_global_load_lds((const global_u32 *)gsrc, (lds_u32 *)rect, 16, 0, 0);
@@ -352,7 +341,6 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
                 unsigned long long smask = __ballot(sub_near);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA has landed
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // rect/ligt written before anyone reads
-                LD_STAMP(td1 = __builtin_amdgcn_s_memtime(); t_dma += td1 - td0;)
                 if (COUNT) tested += (uint32_t)__popcll(smask);
 
                 // ---- 4. surviving subtile pairs, row by row ---------------------------------------
@@ -413,20 +401,11 @@ __global__ __launch_bounds__(MAXT, MINW) void dfire_tiled_pairs(const TiledLaunc
                         if (COUNT) cnt += (t0 < kTiledLutSlow ? 1u : 0u) + (t1 < kTiledLutSlow ? 1u : 0u);
                     }
                 }
-                LD_STAMP(t_loop += __builtin_amdgcn_s_memtime() - td1; t_n++;)
             }
         }
     }
 
     // ---- 5. reduction ----------------------------------------------------------------------------
-    LD_STAMP(if (lane == 0) {
-        atomicAdd(&g_ld_stamps[0], __builtin_amdgcn_s_memtime() - ts0);
-        atomicAdd(&g_ld_stamps[1], t_setup);
-        atomicAdd(&g_ld_stamps[2], t_dma);
-        atomicAdd(&g_ld_stamps[3], t_loop);
-        atomicAdd(&g_ld_stamps[4], t_n);
-        atomicAdd(&g_ld_stamps[5], 1ull);
-    })
     acc += pend0;
     acc += pend1;
     acc = wave_sum(acc);

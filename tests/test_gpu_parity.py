@@ -305,16 +305,20 @@ def test_real_dcparams_goldens_on_gpu(pkg, orc, real_dcparams):
     {"LIGHTDOCK_DFIRE_KERNEL": "tiled"},
     {"LIGHTDOCK_DFIRE_KERNEL": "tiled", "LIGHTDOCK_TILED_WAVES": "3"},
     {"LIGHTDOCK_DFIRE_KERNEL": "tiled", "LIGHTDOCK_TILED_WAVES": "16"},
-    {"LIGHTDOCK_PACKED_CELLS": "1"},
+    {"LIGHTDOCK_DFIRE_KERNEL": "packed"},                                  # the pose-major kernel (what ANM runs use)
+    {"LIGHTDOCK_DFIRE_KERNEL": "packed", "LIGHTDOCK_PACKED_CELLS": "2"},    # ... with half-unit LUT cells
+    {"LIGHTDOCK_DFIRE_KERNEL": "packed", "LIGHTDOCK_PACKED_EPS_SCALE": "8"},
     {"LIGHTDOCK_PACKED_EPS_SCALE": "8"},      # a wider error band: more pairs on the exact path, same results
+    {"LIGHTDOCK_BM_CHUNK": "16"},             # block-major passes of 16 poses, alternating between two streams
+    {"LIGHTDOCK_BM_CHUNK": "16", "LIGHTDOCK_BM_LANES": "1"},
     {"LIGHTDOCK_TILED_SPLIT": "2"},
 ])
 @pytest.mark.parametrize("name", ["1ppe", "1k4c", "2uuy"])
 def test_dfire_kernel_variants_agree(pkg, orc, table, scorers, name, env):
-    """The all-pairs kernel, the box-culled f64 kernel (in several workgroup shapes) and the default
-    kernel (box culling + packed-f32 pair test with exact f64 path, in several settings) are routes to the
-    same sum: all match the oracle, and the in-cutoff pair counts -- which neither culling nor the f32
-    test may change by a single pair -- are identical."""
+    """The all-pairs kernel, the box-culled f64 kernel (in several workgroup shapes), the pose-major packed-f32
+    kernel and the default block-major path (both: box culling + f32 pair test with exact f64 path, in several
+    settings) are routes to the same sum: all match the oracle, and the in-cutoff pair counts -- which neither
+    culling nor the f32 test may change by a single pair -- are identical."""
     torch = pytest.importorskip("torch")
     default_hip, cpu = scorers(name)
     method, rec, lig, kw = case_kwargs(name, orc, table)
@@ -345,9 +349,10 @@ def test_dfire_kernel_variants_agree(pkg, orc, table, scorers, name, env):
     assert np.array_equal(counts[0][:16].astype(np.int64), stats.astype(np.int64))
 
 
+@pytest.mark.parametrize("kernel", [{}, {"LIGHTDOCK_DFIRE_KERNEL": "packed"}, {"LIGHTDOCK_DFIRE_KERNEL": "packed", "LIGHTDOCK_PACKED_CELLS": "2"}])
 @pytest.mark.parametrize("name", ["1ppe", "1k4c", "2uuy"])
-@pytest.mark.parametrize("zeroed", [(19,), (17, 18, 19), (5, 19)])
-def test_bins_that_are_zero_for_the_whole_complex_are_not_read(pkg, orc, table, name, zeroed, monkeypatch):
+@pytest.mark.parametrize("zeroed", [(19,), (17, 18, 19), (5, 19), (0, 1, 19)])
+def test_bins_that_are_zero_for_the_whole_complex_are_not_read(pkg, orc, table, name, zeroed, kernel, monkeypatch):
     """A potential that is 0.0 in a bin for every type pair of the complex (DFIRE's reference state does
     that to the last shell) lets the default kernel skip the table for the pairs of that bin.  The sums
     must equal those of the same kernel reading the zeros (to rounding: the pairs that go through the
@@ -358,6 +363,8 @@ def test_bins_that_are_zero_for_the_whole_complex_are_not_read(pkg, orc, table, 
     for b in zeroed:
         t.reshape(169, 169, 20)[:, :, b] = 0.0
     method, rec, lig, kw = case_kwargs(name, orc, t)
+    for k, v in kernel.items():
+        monkeypatch.setenv(k, v)
     skipping = pkg.Scorer.from_pdb(method, rec, lig, **kw)
     monkeypatch.setenv("LIGHTDOCK_PACKED_ELIDE_ZERO_BINS", "0")
     reading = pkg.Scorer.from_pdb(method, rec, lig, **kw)
@@ -418,12 +425,14 @@ def test_dna_coincident_atoms_score_nan_like_the_reference(pkg, orc, tmp_path):
     assert np.isfinite(want[1]) and abs(got[1] - want[1]) <= 1e-9 * abs(want[1])
 
 
-def test_atoms_outside_the_f32_frame_take_the_exact_path(pkg, orc, table):
+@pytest.mark.parametrize("cells", ["1", "2"])
+def test_atoms_outside_the_f32_frame_take_the_exact_path(pkg, orc, table, cells, monkeypatch):
     """The default DFIRE kernel keeps f32 records in a frame around the receptor; atoms outside it (absurd
     ANM extents here: coefficients of hundreds of angstroms) are flagged and every pair of theirs is
     decided in f64 -- through the per-wave queue or, when that overflows, the all-f64 pass of the wave.
     Energies and in-cutoff pair counts must still equal the oracle's."""
     torch = pytest.importorskip("torch")
+    monkeypatch.setenv("LIGHTDOCK_PACKED_CELLS", cells)
     method, rec, lig, kw = case_kwargs("2uuy", orc, table)
     hip, cpu = pkg.Scorer.from_pdb(method, rec, lig, **kw), orc.Scorer(method, rec, lig, **kw)
     poses = case_positions("2uuy", orc)[:24].copy()
@@ -994,3 +1003,39 @@ def test_bench_plain_command_runs_n_ranks(pkg):
                        capture_output=True, text=True, timeout=300)
     if pkg.device_count() < 2:
         assert r.returncode != 0 and "device(s) visible" in r.stderr
+
+
+@pytest.mark.parametrize("name", ["1ppe", "1k4c"])
+def test_block_major_frame_edges_and_absurd_poses(pkg, scorers, orc, name):
+    """The block-major path keeps f32 records in a frame that holds the receptor + 16 A; a ligand atom outside it is
+    beyond the cutoff of every receptor atom and joins no box.  Poses that put the ligand half outside the frame, far
+    outside, thousands of angstroms away, on top of the receptor (every pair clashing: the exact-path queue is drained
+    over and over) and with a zero or non-finite quaternion must give the oracle's energies and in-cutoff pair counts,
+    and must not disturb their neighbours in the batch."""
+    torch = pytest.importorskip("torch")
+    hip, cpu = scorers(name)
+    assert hip.kernel_info()["pair_kernel_name"] == "dfire_bm_pairs"
+    base = case_positions(name, orc)[:40].copy()
+    rng = np.random.default_rng(3)
+    poses = base.copy()
+    direction = rng.normal(size=(40, 3))
+    direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    reach = np.array([0, 0, 0, 0, 5, 20, 40, 60, 80, 100, 120, 140, 160, 200, 300, 1e3, 1e4, 1e6, 1e9, 1e15])
+    poses[:20, :3] = direction[:20] * reach[:, None]      # from on top of the receptor to absurdly far
+    poses[20, 3:7] = 0.0                                   # zero quaternion: NaN coordinates in the reference, no pair in range
+    poses[21, 3:7] *= 1e-3                                 # tiny and huge norms: rotate divides by the norm
+    poses[22, 3:7] *= 1e3
+    want = np.array([cpu.energy_ex_row(p) for p in poses], dtype=object)
+    want_e = np.array([w[0] for w in want], dtype=np.float64)
+    want_n = np.array([w[1][5] for w in want]).astype(np.int64)
+    dev = torch.device("cuda:0")
+    d_poses = torch.from_numpy(poses).to(dev)
+    d_out = torch.zeros(len(poses), dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(len(poses), dtype=torch.int32, device=dev)
+    hip.energy_batch_device(len(poses), d_poses.data_ptr(), poses.shape[1], d_out.data_ptr(), None, d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_cnt.cpu().numpy().astype(np.int64), want_n)
+    assert rel_err(d_out.cpu().numpy(), want_e) < REL_TOL
+    assert rel_err(hip.energy_batch(poses), want_e) < REL_TOL
+    assert want_n[:4].min() > 10000 and np.all(want_n[15:21] == 0)
+    assert np.array_equal(hip.energy_batch(poses)[23:], hip.energy_batch(base[23:]))     # the neighbours: bit for bit what they are alone
