@@ -7,6 +7,7 @@
 // explicit fmas.  No MFMA (lookup/reduction).
 #include "dfire_bm.hpp"
 
+#include <algorithm>
 #include <cmath>
 
 #include "dfire_device.hpp"
@@ -37,6 +38,13 @@ __device__ __forceinline__ long long bm_pose_of(BmArgs *T, size_t listed) {
     const size_t pose = T->pose_list ? (size_t)T->pose_list[T->first + listed] : T->first + listed;
     if (T->active != nullptr && T->active[pose] == 0) return -1;
     return (long long)pose;
+}
+
+// rows of this launch that exist: all n_poses of a plain batch; with a GSO list, what the device-side count leaves of them
+__device__ __forceinline__ size_t bm_rows(BmArgs *T) {
+    if (T->pose_count == nullptr) return T->n_poses;
+    const size_t count = (size_t)*T->pose_count;
+    return count <= T->first ? 0 : (count - T->first < T->n_poses ? count - T->first : T->n_poses);
 }
 
 // The f32 affine map of a pose, applied in ONE operation order wherever a ligand atom is posed in f32 (culling
@@ -92,31 +100,32 @@ __device__ __forceinline__ ExactCtx bm_exact_ctx(BmArgs *T, size_t pose) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
-    const size_t listed = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (listed >= T->n_poses) return;
-    const long long p = bm_pose_of(T, listed);
-    if (p < 0) return;
-    const size_t pose = (size_t)p;
-    const double *row = T->poses + pose * T->stride;
-    const double tx = row[0], ty = row[1], tz = row[2], w = row[3], x = row[4], y = row[5], z = row[6];
-    const double n2 = w * w + x * x + y * y + z * z;
-    const double k = kBmKappa / n2;
-    float *o = T->rt + pose * 12;
-    o[0] = (float)(k * (w * w + x * x - y * y - z * z));
-    o[1] = (float)(k * 2.0 * (x * y - w * z));
-    o[2] = (float)(k * 2.0 * (x * z + w * y));
-    o[3] = (float)(kBmKappa * (tx - T->m.cx));
-    o[4] = (float)(k * 2.0 * (x * y + w * z));
-    o[5] = (float)(k * (w * w - x * x + y * y - z * z));
-    o[6] = (float)(k * 2.0 * (y * z - w * x));
-    o[7] = (float)(kBmKappa * (ty - T->m.cy));
-    o[8] = (float)(k * 2.0 * (x * z - w * y));
-    o[9] = (float)(k * 2.0 * (y * z + w * x));
-    o[10] = (float)(k * (w * w - x * x - y * y + z * z));
-    o[11] = (float)(kBmKappa * (tz - T->m.cz));
-    if (T->exact_fix) T->exact_fix[pose] = 0;
-    if (T->exact_count) T->exact_count[pose] = 0;
-    if (T->exact_pairs) T->exact_pairs[pose] = 0;
+    const size_t rows = bm_rows(T);   // (a launch sized for every glowworm of a GSO costs what the glowworms that moved cost)
+    for (size_t listed = (size_t)blockIdx.x * 256 + threadIdx.x; listed < rows; listed += (size_t)gridDim.x * 256) {
+        const long long p = bm_pose_of(T, listed);
+        if (p < 0) continue;
+        const size_t pose = (size_t)p;
+        const double *row = T->poses + pose * T->stride;
+        const double tx = row[0], ty = row[1], tz = row[2], w = row[3], x = row[4], y = row[5], z = row[6];
+        const double n2 = w * w + x * x + y * y + z * z;
+        const double k = kBmKappa / n2;
+        float *o = T->rt + pose * 12;
+        o[0] = (float)(k * (w * w + x * x - y * y - z * z));
+        o[1] = (float)(k * 2.0 * (x * y - w * z));
+        o[2] = (float)(k * 2.0 * (x * z + w * y));
+        o[3] = (float)(kBmKappa * (tx - T->m.cx));
+        o[4] = (float)(k * 2.0 * (x * y + w * z));
+        o[5] = (float)(k * (w * w - x * x + y * y - z * z));
+        o[6] = (float)(k * 2.0 * (y * z - w * x));
+        o[7] = (float)(kBmKappa * (ty - T->m.cy));
+        o[8] = (float)(k * 2.0 * (x * z - w * y));
+        o[9] = (float)(k * 2.0 * (y * z + w * x));
+        o[10] = (float)(k * (w * w - x * x - y * y + z * z));
+        o[11] = (float)(kBmKappa * (tz - T->m.cz));
+        if (T->exact_fix) T->exact_fix[pose] = 0;
+        if (T->exact_count) T->exact_count[pose] = 0;
+        if (T->exact_pairs) T->exact_pairs[pose] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -141,17 +150,19 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
     unsigned long long *s_mask = s_cull + (size_t)wave * kBmCullPoses * n_rt;
-    const size_t item = (size_t)blockIdx.x * kBmCullWaves + wave;   // the waves of a workgroup are independent (no barrier)
+    const size_t rows = bm_rows(T);
+    const size_t n_items = (rows + kBmCullPoses - 1) / kBmCullPoses * (size_t)n_lt;
+    const float ubound = T->m.ubound, pad = T->m.box_pad;
+    const int bj = lane & 7;
+    // the waves of a workgroup are independent (no barrier); a wave walks items until the launch's rows are done
+    for (size_t item = (size_t)blockIdx.x * kBmCullWaves + wave; item < n_items; item += (size_t)gridDim.x * kBmCullWaves) {
     const size_t group = item / (unsigned)n_lt;
     const int lt = (int)(item % (unsigned)n_lt);
     const size_t listed0 = group * kBmCullPoses;
-    if (listed0 >= T->n_poses) return;
 
     const int la = lt * 64 + lane;
     const float4 loc = reinterpret_cast<const float4 *>(T->m.lig_local)[la];
     const bool valid = loc.w != 0.f;
-    const int bj = lane & 7;
-    const float ubound = T->m.ubound, pad = T->m.box_pad;
     // this lane's receptor tile box (the first 64 tiles; larger receptors load the rest per pose)
     TiledBox my_tile = TiledBox{INFINITY, INFINITY, INFINITY, 0.f, -INFINITY, -INFINITY, -INFINITY, 0.f};
     if (lane < n_rt) my_tile = T->m.rec_tile[lane];
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
 #pragma unroll
     for (int g = 0; g < kBmCullPoses; g++) {
         const size_t listed = listed0 + g;
-        pose_of[g] = listed < T->n_poses ? bm_pose_of(T, listed) : -1;
+        pose_of[g] = listed < rows ? bm_pose_of(T, listed) : -1;
         if (pose_of[g] < 0) continue;
         const size_t pose = (size_t)pose_of[g];
         const Affine A = bm_load_affine(T->rt, pose);
@@ -262,48 +273,71 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         for (int g = 0; g < kBmCullPoses; g++)
             if (pose_of[g] >= 0) T->vis_count[(size_t)pose_of[g] * n_lt + lt] = n_vis[g];
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the masks in LDS are read before the next item clears them
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// dfire_bm_plan: every tile pair's entries cut into parts of kBmPartEntries; a JOB = (tile pair, part, ligand subtile a)
-// is what one wave of dfire_bm_pairs walks.
+// dfire_bm_plan: every tile pair's entries cut into parts of P entries; a JOB = (tile pair, part, partial-sum row) is
+// what one wave of dfire_bm_pairs walks.  P = kBmPartEntries for a large launch (the longer a job, the more batches
+// share each staging of a block's table rows); a launch with few entries -- the late steps of a GSO run, when few
+// glowworms still move -- is cut finer so that its jobs still spread over every wave of the chip.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void dfire_bm_plan(const BmLaunch launch_arguments) {
-    // One workgroup.  Jobs are listed longest first (by entries, in classes of 64): the persistent waves of
+    // One workgroup.  Jobs are listed longest first (by entries, in 16 classes): the persistent waves of
     // dfire_bm_pairs draw them in that order, so the launch ends on its shortest jobs.
     BmArgs *T = LD_BM_ARGS;
-    __shared__ uint32_t s_class[18];   // [c]: parts of c * 64 - 63 .. c * 64 entries; then cursors
+    __shared__ uint32_t s_class[18];   // [c]: parts of more than (c - 1) P / 16 and at most c P / 16 entries; then cursors
+    __shared__ uint32_t s_total;
     const int tid = threadIdx.x;
     const uint32_t n_tp = (uint32_t)(T->m.lig.n_tiles * T->m.rec_n_tiles);
     if (tid < 18) s_class[tid] = 0;
+    if (tid == 0) s_total = 0;
     __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t tp = tid; tp < n_tp; tp += 1024) mine += T->tp_count[tp];
+    if (mine) atomicAdd(&s_total, mine);
+    __syncthreads();
+    // about one (tile pair, part) pair per wave of the pair kernel, i.e. kBmJobRows jobs per wave
+    const uint32_t waves = (uint32_t)(T->pairs_groups > 0 ? T->pairs_groups : 256) * kBmWaves;
+    uint32_t P = (s_total / waves + 63u) / 64u * 64u;
+    P = P < 64u ? 64u : P > (uint32_t)kBmPartEntries ? (uint32_t)kBmPartEntries : P;
+    const uint32_t step = P / 16u;
     for (uint32_t tp = tid; tp < n_tp; tp += 1024) {
         const uint32_t n = T->tp_count[tp];
         if (n == 0) continue;
-        const uint32_t full = n / kBmPartEntries, rest = n % kBmPartEntries;
-        if (full) atomicAdd(&s_class[kBmPartEntries / 64], full);
-        if (rest) atomicAdd(&s_class[(rest + 63) / 64], 1u);
+        const uint32_t full = n / P, rest = n % P;
+        if (full) atomicAdd(&s_class[16], full);
+        if (rest) atomicAdd(&s_class[(rest + step - 1) / step], 1u);
     }
     __syncthreads();
     if (tid == 0) {
         uint32_t at = 0;
-        for (int c = kBmPartEntries / 64; c >= 1; c--) {
+        for (int c = 16; c >= 1; c--) {
             const uint32_t k = s_class[c];
             s_class[c] = at;
             at += k;
         }
-        *T->job_count = at;
+        T->job_count[0] = at;
+        T->job_count[2] = P;
     }
     __syncthreads();
     for (uint32_t tp = tid; tp < n_tp; tp += 1024) {
         const uint32_t n = T->tp_count[tp];
         if (n == 0) continue;
-        const uint32_t full = n / kBmPartEntries, rest = n % kBmPartEntries;
+        const uint32_t full = n / P, rest = n % P;
         if (full) {
-            const uint32_t at = atomicAdd(&s_class[kBmPartEntries / 64], full);
-            for (uint32_t k = 0; k < full; k++) T->jobs[at + k] = tp << 8 | k;   // parts <= 255: cap <= 255 * kBmPartEntries (scorer.cpp)
+            const uint32_t at = atomicAdd(&s_class[16], full);
+            for (uint32_t k = 0; k < full; k++) {
+                T->jobs[2 * (at + k)] = tp;
+                T->jobs[2 * (at + k) + 1] = k * P;
+            }
         }
-        if (rest) T->jobs[atomicAdd(&s_class[(rest + 63) / 64], 1u)] = tp << 8 | full;
+        if (rest) {
+            const uint32_t at = atomicAdd(&s_class[(rest + step - 1) / step], 1u);
+            T->jobs[2 * at] = tp;
+            T->jobs[2 * at + 1] = full * P;
+        }
     }
 }
 
@@ -373,7 +407,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
     if (lane < 4) reinterpret_cast<uint32_t *>(WS.cube + kBmCubeRows * kBmRowBytes)[lane] = 0u;   // the zero slot behind the last row
     __syncthreads();
     const unsigned char *cube = WS.cube;
-    const uint32_t n_jobs = *T->job_count * (uint32_t)kBmJobRows;
+    const uint32_t n_jobs = T->job_count[0] * (uint32_t)kBmJobRows, part_entries = T->job_count[2];
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long dbg_jobs = 0, dbg_batches = 0, dbg_t_batch = 0, dbg_t_drain = 0, dbg_t_scan = 0, dbg_drains = 0;
 
@@ -382,15 +416,15 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
         if (lane == 0) job = atomicAdd(T->job_next, 1u);
         job = (uint32_t)__builtin_amdgcn_readfirstlane((int)job);
         if (job >= n_jobs) break;
-        const uint32_t jd = T->jobs[job / (uint32_t)kBmJobRows];
+        const uint32_t jd = job / (uint32_t)kBmJobRows;
         const int jrow = (int)(job % (uint32_t)kBmJobRows);   // partial-sum row of the entry: (job row of the tile, part of its blocks)
         const int arow = jrow / kBmHalves, b_lo = (jrow % kBmHalves) * (8 / kBmHalves);
         const int a = arow / kBmSplit, la0 = (arow % kBmSplit) * kBmLig;   // ligand subtile a, its atoms la0 .. la0 + kBmLig - 1
         const uint32_t b_mask = ((1u << (8 / kBmHalves)) - 1u) << b_lo;      // the job's blocks (a, b_lo .. b_lo + 8 / kBmHalves - 1)
-        const size_t tp = jd >> 8;
-        const uint32_t lo = (jd & 255u) * (uint32_t)kBmPartEntries;
+        const size_t tp = T->jobs[2 * jd];
+        const uint32_t lo = T->jobs[2 * jd + 1];
         const uint32_t n = T->tp_count[tp];
-        const uint32_t hi = n < lo + (uint32_t)kBmPartEntries ? n : lo + (uint32_t)kBmPartEntries;
+        const uint32_t hi = n < lo + part_entries ? n : lo + part_entries;
         const int n_chunks = (int)((hi - lo + 63) / 64);
         const int lt = (int)(tp / (unsigned)n_rt), RT = (int)(tp % (unsigned)n_rt);
         const int ls = lt * 8 + a;
@@ -647,8 +681,10 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
     int span = kBmJobRows;
     while (span < rows && span < 512) span <<= 1;
     const int per_wg = 512 / span, sub = tid / span, r0 = tid % span;
-    const size_t listed = (size_t)blockIdx.x * per_wg + sub;
-    const long long pp = listed < T->n_poses ? bm_pose_of(T, listed) : -1;
+    const size_t n_rows = bm_rows(T);
+    for (size_t first_row = (size_t)blockIdx.x * per_wg; first_row < n_rows; first_row += (size_t)gridDim.x * per_wg) {
+    const size_t listed = first_row + sub;
+    const long long pp = listed < n_rows ? bm_pose_of(T, listed) : -1;
     const size_t pose = pp < 0 ? 0 : (size_t)pp;
     double s = 0.0;
     uint32_t cnt = 0, tested = 0;
@@ -707,6 +743,8 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
             if (T->exact_partial) T->exact_partial[pose] = T->exact_pairs[pose];
         }
     }
+    __syncthreads();   // s_sum is reused by the next rows
+    }
 }
 
 }  // namespace
@@ -715,14 +753,14 @@ size_t bm_pairs_lds_bytes() { return sizeof(BmShared); }
 
 hipError_t launch_bm_pose(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    hipLaunchKernelGGL(dfire_bm_pose, dim3((unsigned)((t.n_poses + 255) / 256)), dim3(256), 0, stream, t);
+    hipLaunchKernelGGL(dfire_bm_pose, dim3((unsigned)std::min<size_t>((t.n_poses + 255) / 256, 2048)), dim3(256), 0, stream, t);
     return hipGetLastError();
 }
 
 hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    const size_t blocks = ((t.n_poses + kBmCullPoses - 1) / kBmCullPoses * (size_t)t.m.lig.n_tiles + kBmCullWaves - 1) / kBmCullWaves;
-    if (blocks > 0x7fffffffULL || t.m.rec_n_tiles > 255) return hipErrorInvalidValue;
+    const size_t blocks = std::min<size_t>(((t.n_poses + kBmCullPoses - 1) / kBmCullPoses * (size_t)t.m.lig.n_tiles + kBmCullWaves - 1) / kBmCullWaves, 32768);
+    if (t.m.rec_n_tiles > 255) return hipErrorInvalidValue;
     const size_t lds = (size_t)kBmCullWaves * kBmCullPoses * t.m.rec_n_tiles * sizeof(unsigned long long);
     if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_cull<true>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
     else hipLaunchKernelGGL((dfire_bm_cull<false>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
@@ -744,7 +782,7 @@ hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t stream) {
     int span = kBmJobRows;
     while (span < rows && span < 512) span <<= 1;
     const size_t per_wg = 512 / span;
-    const unsigned blocks = (unsigned)((t.n_poses + per_wg - 1) / per_wg);
+    const unsigned blocks = (unsigned)std::min<size_t>((t.n_poses + per_wg - 1) / per_wg, 16384);
     if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_gather<true>), dim3(blocks), dim3(512), 0, stream, t);
     else hipLaunchKernelGGL((dfire_bm_gather<false>), dim3(blocks), dim3(512), 0, stream, t);
     return hipGetLastError();

@@ -114,8 +114,8 @@ struct BmLaunch {
     float *ent_rt = nullptr;               // [tile pair][cap][12]: the entry's pose as the f32 affine map
     double *ent_partial = nullptr;         // [tile pair][kBmJobRows][cap]
     uint32_t *ent_count = nullptr;         // [tile pair][kBmJobRows][cap] or nullptr (counting launches)
-    uint32_t *jobs = nullptr;              // [tile pairs * parts]: tile pair << 8 | part, written by dfire_bm_plan
-    uint32_t *job_count = nullptr;         // [2], zeroed per launch: jobs listed, jobs drawn (job_next = job_count + 1)
+    uint32_t *jobs = nullptr;              // [(tile pair, part)][2]: tile pair, first entry; written by dfire_bm_plan
+    uint32_t *job_count = nullptr;         // [4], zeroed per launch: (tile pair, part) pairs listed, jobs drawn (job_next = job_count + 1), entries per part
     uint32_t *job_next = nullptr;
     int pairs_groups = 0;                  // workgroups of dfire_bm_pairs (0: one per CU of an MI355X)
     unsigned long long *debug = nullptr;   // diagnostics (LIGHTDOCK_BM_DEBUG): per wave of dfire_bm_pairs {start, end (100 MHz), jobs, batches}

@@ -817,10 +817,9 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     const size_t tile_pairs = (size_t)rec.n_tiles * lig.n_tiles;
     size_t chunk = ((size_t)4 << 30) / ((60 + 12 * kBmJobRows) * tile_pairs);   // two such workspaces exist (two passes in flight)
     chunk = std::max<size_t>(kBmPartEntries, chunk / kBmPartEntries * kBmPartEntries);
-    chunk = std::min<size_t>(chunk, (size_t)255 * kBmPartEntries);   // a job names its part in 8 bits
     if (const char *e = std::getenv("LIGHTDOCK_BM_CHUNK")) {
         const long v = std::atol(e);
-        if (v >= 1) chunk = std::min<size_t>((size_t)v, (size_t)255 * kBmPartEntries);
+        if (v >= 1) chunk = (size_t)v;
     }
     bm_chunk_ = chunk;
     {
@@ -846,7 +845,7 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
                     const uint32_t *d_count) {
     const size_t tile_pairs = (size_t)bm_.lig.n_tiles * bm_.rec_n_tiles;
     const size_t cap = bm_pass_poses(n);
-    const size_t jobs_per_lane = tile_pairs * ((cap + kBmPartEntries - 1) / kBmPartEntries);
+    const size_t jobs_per_lane = tile_pairs * (cap / 64 + 1) * 2;
     BmLaunch t;
     t.m = bm_;
     t.poses = d_poses;
@@ -888,7 +887,7 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         const size_t w = (size_t)lane;   // workspace set
         t.first = off;
         t.n_poses = std::min(cap, n - off);
-        t.tp_count = static_cast<uint32_t *>(ws_bm_tp_count_.ptr) + w * (tile_pairs + 2);
+        t.tp_count = static_cast<uint32_t *>(ws_bm_tp_count_.ptr) + w * (tile_pairs + 4);
         t.job_count = t.tp_count + tile_pairs;
         t.job_next = t.tp_count + tile_pairs + 1;
         t.jobs = static_cast<uint32_t *>(ws_bm_jobs_.ptr) + w * jobs_per_lane;
@@ -897,7 +896,7 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         t.ent_rt = static_cast<float *>(ws_bm_ent_rt_.ptr) + w * tile_pairs * cap * 12;
         t.ent_partial = static_cast<double *>(ws_bm_ent_partial_.ptr) + w * tile_pairs * kBmJobRows * cap;
         t.ent_count = counts ? static_cast<uint32_t *>(ws_bm_ent_count_.ptr) + w * tile_pairs * kBmJobRows * cap : nullptr;
-        hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + 2) * sizeof(uint32_t), st), "hipMemsetAsync(tile pair counts)");
+        hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + 4) * sizeof(uint32_t), st), "hipMemsetAsync(tile pair counts)");
         hip_check(launch_bm_pose(t, st), "launch dfire_bm_pose");
         hip_check(launch_bm_cull(t, st), "launch dfire_bm_cull");
         hip_check(launch_bm_pairs(t, st), "launch dfire_bm_pairs");
@@ -1013,8 +1012,8 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         const size_t n = n_poses, n_lt = (size_t)bm_.lig.n_tiles, n_rt = (size_t)bm_.rec_n_tiles, tile_pairs = n_lt * n_rt;
         const size_t cap = bm_pass_poses(n) * 2;   // two passes in flight (run_bm), each with its own entry workspace
         ws_bm_rt_.reserve(n * 12 * sizeof(float));
-        ws_bm_tp_count_.reserve(2 * (tile_pairs + 2) * sizeof(uint32_t));   // + jobs listed, jobs drawn
-        ws_bm_jobs_.reserve(2 * tile_pairs * ((cap / 2 + kBmPartEntries - 1) / kBmPartEntries) * sizeof(uint32_t));
+        ws_bm_tp_count_.reserve(2 * (tile_pairs + 4) * sizeof(uint32_t));   // + parts listed, jobs drawn, entries per part
+        ws_bm_jobs_.reserve(2 * (tile_pairs * (cap / 2 / 64 + 1)) * 2 * sizeof(uint32_t));   // at most entries / 64 + tile pairs parts
         ws_bm_ent_pose_.reserve(tile_pairs * cap * sizeof(uint32_t));
         ws_bm_ent_mask_.reserve(tile_pairs * cap * sizeof(unsigned long long));
         ws_bm_ent_rt_.reserve(tile_pairs * cap * 12 * sizeof(float));
