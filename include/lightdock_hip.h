@@ -135,6 +135,16 @@ int ld_dfire_bin_lut(uint8_t *lut_out /* 901 */, double *steps_out /* 21 */, dou
  * eps_out: the bound on |D_f32 - 4 d2| (units of 4 d2) the LUT was built for.
  * words_out: 1028 * cells_per_unit entries; cells_per_unit is 1 or 2. */
 int ld_dfire_packed_lut(int cells_per_unit, double ubound, uint32_t *words_out, double *eps_out);
+/* The cell LUT of the block-major DFIRE kernels (kernels/dfire_bm.hpp; host-side, no GPU), for tests.  The kernel
+ * computes E = 14583.5 - 64 d2 in f32 (error below eps_cells / 2, which depends on the frame `ubound` in record units
+ * of 1/8 A and on the ligand's largest |local coordinate| `lig_extent` in A) and reads codes_out[floor(E)], E < 0 reading
+ * cell 0:
+ *   code 0                       every f64 d2 that can produce this cell is beyond the cutoff (src/dfire.rs:334)
+ *   code 8 * slot, slot 1..21    every such d2 has the bin of that slot (bins 2..20 -> slots 1..19, bins 0, 1 -> slots
+ *                                20, 21; src/dfire.rs:336-337) and is inside the cutoff
+ *   code 176                     flagged: the pair reads 0.0 and is recomputed in f64
+ * codes_out: 14592 entries. */
+int ld_dfire_bm_lut(double ubound, double lig_extent, uint8_t *codes_out, double *eps_cells_out);
 /* The atom order the tiled DFIRE kernel uses (host-side, no GPU): order_out[slot] = original atom
  * index, UINT32_MAX for padding; length = ceil(n/64)*64.  Consecutive 8 slots ("subtile") and 64
  * slots ("tile") are spatially compact; padding only at the tail.  The energy is a plain sum over

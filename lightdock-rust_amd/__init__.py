@@ -128,6 +128,7 @@ def load_library():
     lib.ld_model_destroy.argtypes = [vp]
     lib.ld_dfire_bin_lut.argtypes = [vp, vp, C.POINTER(C.c_double)]
     lib.ld_dfire_packed_lut.argtypes = [C.c_int, C.c_double, vp, C.POINTER(C.c_double)]
+    lib.ld_dfire_bm_lut.argtypes = [C.c_double, C.c_double, vp, C.POINTER(C.c_double)]
     lib.ld_stdrng_key.argtypes = [C.c_uint64, vp]
     lib.ld_spatial_tile_order.restype = sz
     lib.ld_spatial_tile_order.argtypes = [vp, sz, vp]
@@ -221,6 +222,14 @@ def dfire_packed_lut(cells_per_unit=2, ubound=256.0):
     eps = C.c_double()
     _check(load_library().ld_dfire_packed_lut(cells_per_unit, ubound, _ptr(words), C.byref(eps)))
     return words, eps.value
+
+
+def dfire_bm_lut(ubound=1024.0, lig_extent=45.0):
+    """(codes, eps in LUT cells) of the block-major DFIRE kernel's cell LUT, see ld_dfire_bm_lut in the header."""
+    codes = np.zeros(14592, dtype=np.uint8)
+    eps = C.c_double()
+    _check(load_library().ld_dfire_bm_lut(C.c_double(ubound), C.c_double(lig_extent), _ptr(codes), C.byref(eps)))
+    return codes, eps.value
 
 
 def spatial_tile_order(xyz):

@@ -174,6 +174,15 @@ int ld_dfire_packed_lut(int cells_per_unit, double ubound, uint32_t *words_out, 
         if (eps_out) *eps_out = eps;
     });
 }
+int ld_dfire_bm_lut(double ubound, double lig_extent, uint8_t *codes_out, double *eps_cells_out) {
+    return guarded([&] {
+        if (!(ubound > 0.0) || !(lig_extent >= 0.0)) throw ld::Error(LD_ERR_INVALID, "ubound must be positive, lig_extent non-negative");
+        const double eps = ld::dfire_bm_error_bound(ubound, lig_extent);
+        const std::vector<uint8_t> codes = ld::build_bm_lut(eps);
+        if (codes_out) std::memcpy(codes_out, codes.data(), codes.size());
+        if (eps_cells_out) *eps_cells_out = eps;
+    });
+}
 size_t ld_spatial_tile_order(const double *xyz, size_t n, uint32_t *order_out) {
     size_t len = 0;
     guarded([&] {

@@ -353,7 +353,7 @@ struct BmWaveShared {
     uint32_t queue[kBmQueue];                      // pairs for the exact path
 };
 struct BmShared {
-    unsigned char lut[kBmLutBytes];   // indexed from the far end: cell' = floor(kBmCellMax + 1/2 - 64 d2), everything further reads cell' 0
+    unsigned char lut[kBmLutBytes];   // indexed from the far end: cell' = floor(kBmCellZero + 1/2 - 64 d2), everything further reads cell' 0
     BmWaveShared w[kBmWaves];
 };
 
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
             // A block with an atom that has an interface-flag slot also queues its pairs closer than 2.5 A (bins 0 and 1,
             // whose slots are the last two of a row) for the exact path, which sets the flags (src/dfire.rs:339-342).
             const uint32_t flag_from = lig_tracked || __builtin_amdgcn_readlane((int)my_tracked, b) != 0 ? kBmNearCode : kBmFlagged;
-            constexpr float seed = kBmCellMax + 0.5f;
+            constexpr float seed = (float)kBmCellZero + 0.5f;
             // ---- the job's entries that hold block (a, b), in entry order
             uint32_t n_items = 0;
             for (int k = 0; k < n_chunks; k++) {

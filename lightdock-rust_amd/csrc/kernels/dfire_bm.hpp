@@ -41,6 +41,7 @@ constexpr double kBmKappa = 8.0;             // records hold fl32(kappa (x - c))
 constexpr int kBmCutCell = 900 * kBmCells;   // the cutoff 4 d2 = 900
 constexpr int kBmLutBytes = 14592;           // cells 0 .. 14591: everything beyond kBmCutCell + eps reads "miss"
 constexpr float kBmCellMax = 14591.0f;
+constexpr int kBmCellZero = 14583;            // the cell of 64 d2 = 0: E = kBmCellZero + 1/2 - 64 d2 stays inside the LUT for any error below 8 cells
 constexpr int kBmRowSlots = 22;              // slot 0 = 0.0 (miss), slots 1..19 = bins 2..20 (20 = the read past the row at r = 15.0), slots 20, 21 = bins 0, 1
 constexpr int kBmRowBytes = kBmRowSlots * 8;
 #ifndef LD_BM_WAVES

@@ -657,8 +657,9 @@ double dfire_bm_error_bound(double ubound, double lig_extent) {
     return 2.0 * eps;  // twice the bound, LUT cells
 }
 
-// The kernel computes E = kBmCellMax + 1/2 - 64 d2 (f32) and reads cell' = floor(E), everything further than the LUT
-// reaches (E < 0) reading cell' 0.  Cell' k' = kBmCellMax - k holds the pairs with 64 d2 within (k - 1/2 - eps, k + 1/2 + eps),
+// The kernel computes E = kBmCellZero + 1/2 - 64 d2 (f32) and reads cell' = floor(E), everything further than the LUT
+// reaches (E < 0) reading cell' 0; the cells above kBmCellZero are what an error of up to 8 cells can turn a distance near 0
+// into.  Cell' k' = kBmCellZero - k holds the pairs with 64 d2 within (k - 1/2 - eps, k + 1/2 + eps),
 // i.e. a true 4 d2 within ((k - 1/2 - eps) / 16, (k + 1/2 + eps) / 16).  A cell with ONE answer for that whole interval
 // carries the bin's slot in the block's table rows (bm_slot_of_bin(bin) * 8; 0 = "miss" beyond the cutoff or a bin that is
 // zero for the whole complex); a cell with a bin step or the cutoff inside is flagged: the kernel reads 0.0 and recomputes
@@ -670,8 +671,8 @@ std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins) {
     if (!(iface_scaled < 4.0 * b.step[2] && iface_scaled >= 4.0 * b.step[1]))
         throw Error(LD_ERR_INVALID, "DFIRE block-major LUT: the interface distance is not inside bin 1");
     std::vector<uint8_t> codes(kBmLutBytes, 0);
-    for (int k = 0; k < kBmLutBytes; k++) {
-        uint8_t &code = codes[kBmLutBytes - 1 - k];
+    for (int k = kBmCellZero - (kBmLutBytes - 1); k <= kBmCellZero; k++) {
+        uint8_t &code = codes[kBmCellZero - k];
         const double ilo = (k - 0.5 - eps_cells) / kBmCells, ihi = (k + 0.5 + eps_cells) / kBmCells;
         if (ilo > 900.0) continue;  // beyond the cutoff for sure
         bool flagged = ihi >= 900.0;

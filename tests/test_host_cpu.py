@@ -439,3 +439,51 @@ def test_packed_kernel_cell_lut_decides_like_the_reference(pkg, orc, cells):
     # the cells the pair loop handles without any branch hold one bin each, over their whole interval
     flagged = int(((words >> 30) & 1).sum())
     assert flagged < 40 * cells + 10
+
+
+@pytest.mark.parametrize("ubound,extent", [(1024.0, 45.0), (512.0, 20.0), (4096.0, 120.0)])
+def test_block_major_cell_lut_decides_like_the_reference(pkg, orc, ubound, extent):
+    """The block-major DFIRE kernels test pairs in f32: E = 14583.5 - 64 d2 with an error below eps/2 LUT cells (eps
+    carries a factor 2), cell = floor(E), everything below 0 reading cell 0.  Whatever f32 value a true f64 distance can
+    turn into, the code of its cell must give the reference's answer -- bin (src/dfire.rs:336-337) or beyond the
+    cutoff (:334) -- or send the pair to the exact f64 path; and every pair that can set an interface flag (:339) must
+    carry a code of bins 0 / 1, by which a block with tracked atoms recognises it."""
+    codes, eps = pkg.dfire_bm_lut(ubound, extent)
+    _, steps, iface = pkg.dfire_bin_lut()
+    assert 0.0 < eps < 8.0
+    assert codes[0] == 0 and len(codes) == 14592
+    FLAGGED, NEAR = 176, 160
+
+    def slot(b):
+        return b - 1 if b >= 2 else 20 + b
+
+    rng = np.random.default_rng(5)
+    cand = list(rng.uniform(0.0, 1100.0, 30000)) + list(rng.uniform(0.0, 40.0, 4000))
+    e4 = eps / 16.0     # eps in units of 4 d2
+    for s in list(steps[1:]) + [iface, 225.0]:
+        cand += [4.0 * s + d for d in (-0.3, -0.1, -2 * e4, -e4, -e4 / 2, -1e-9, 0.0, 1e-9, e4 / 2, e4, 2 * e4, 0.1, 0.3)]
+    cand += [2000.0, 1e4, 1e6, 1e30, float("inf")]
+    plain = flagged = miss = 0
+    for d4 in cand:
+        if d4 < 0.0:
+            continue
+        d2 = d4 / 4.0
+        want = orc.dfire_bin(d2) if d2 <= 225.0 else None
+        for err in (-eps / 2, -eps / 4, 0.0, eps / 4, eps / 2):
+            E = np.float32(14583.5) - np.float32(16.0 * d4 + err) if np.isfinite(d4) else np.float32(-np.inf)
+            c = int(E) if E >= 0 else 0              # v_cvt_u32_f32: negative and NaN -> 0
+            code = int(codes[c])
+            if code == FLAGGED:
+                flagged += 1                        # exact f64 path: right by construction
+            elif code == 0:
+                miss += 1
+                assert want is None, (d4, err)
+            else:
+                plain += 1
+                assert want is not None and code == 8 * slot(want), (d4, err, code)
+            if d2 <= iface:                         # a pair that sets interface flags: recognisable by its code
+                assert code >= NEAR, (d4, err, code)
+    assert plain > 100000 and flagged > 10 and miss > 1000
+    # one flagged cell per bin step and at the cutoff while eps < 1/2 cell; a few more for larger frames
+    n_flagged = int((codes == FLAGGED).sum())
+    assert 20 <= n_flagged <= 21 * (1 + 2 * int(np.ceil(max(eps - 0.5, 0.0)))) + 2 * int(np.ceil(eps)) + 2      # (the last step is the cutoff)
