@@ -234,18 +234,19 @@ __global__ __launch_bounds__(kBlockThreads) void pose_energy_pairs(const PairLau
             }
         } else {
             const double lq = P.lig.charge[la], le = P.lig.well_depth[la], lr = P.lig.radius[la];
-            double closest = 1.0;  // smallest d2 seen: coincident atoms make the reference's score NaN, see below
+            bool coincident = false;  // a pair whose 12-6 term is NaN in the reference, see below
             for (int j = j_begin; j < j_end; j++) {
                 const DnaRec a = rec[j];
                 const double dx = a.x - lx, dy = a.y - ly, dz = a.z - lz;
                 const double d2 = dx * dx + dy * dy + dz * dz;  // src/dna.rs:476-478
-                closest = fmin(closest, d2);
                 if (d2 <= kElecCutoff2) {                         // src/dna.rs:481-491
-                    // 1/d2 by v_rcp_f64 (good to ~2^-26) + one Newton step (error squared: ~1 ulp) instead of
-                    // two correctly rounded f64 divisions: the energy is continuous in these terms (all cutoff
-                    // tests above/below use the exact d2), so this stays ~1e-15 relative -- the 8 printed
-                    // decimals of the reference's gso files and the 1e-9 oracle tolerance are unaffected --
-                    // at half the instruction count.  (A second step changes nothing measurable and costs 5 %.)
+                    // 1/d2 by v_rcp_f64 + one Newton step instead of two correctly rounded f64 divisions.  The ISA
+                    // promises v_rcp_f64 only about 2^-24 relative, so one step guarantees about 2^-47 (tens of ulps)
+                    // per term, not 1 ulp.  The energy is continuous in these terms (every cutoff test above/below uses
+                    // the exact d2) and the tests hold it to 1e-9 against the oracle (observed ~1e-13 on the 200
+                    // 1azp poses, whose electrostatic sum cancels to a few per cent of its terms) and to the 8
+                    // printed decimals of the reference's gso files -- at half the instruction count.  (A second
+                    // step changes no printed digit and costs 5 %.)
                     const double r0 = __builtin_amdgcn_rcp(d2);
                     const double inv = __builtin_fma(r0, __builtin_fma(-d2, r0, 1.0), r0);
                     double e = (a.charge * lq) * inv;
@@ -262,6 +263,15 @@ __global__ __launch_bounds__(kBlockThreads) void pose_energy_pairs(const PairLau
                         double k = vdw_energy * (p6 * p6 - 2.0 * p6);
                         k = fmin(k, kVdwMax);
                         acc1 += k;
+                        // Two atoms on (almost) the same spot: the reference's p6 = R^6 / d2^3 (src/dna.rs:498) is inf when
+                        // d2^3 underflows or the quotient overflows, and k = e * (inf - inf) = NaN, which its ordered
+                        // `k > VDW_CUTOFF` keeps (:499-503): the score is NaN.  A p6 that is huge but finite gives
+                        // k = inf, which it clamps.  fmin above turns both into the clamp value: redo the reference's own
+                        // division for such pairs (none in any real pose) and keep the NaN where it has one.
+                        if (__builtin_expect(d2 < 1.0e-90, 0)) {
+                            const double p6_ref = rr6 / (d2 * (d2 * d2));
+                            if (!(p6_ref <= 1.7976931348623157e308)) coincident = true;
+                        }
                         if (d2 <= P.iface_d2) {  // src/dna.rs:507-510
                             if (a.slot >= 0) atomicOr(&pose_flags[a.slot >> 5], 1u << (a.slot & 31));
                             lflag = true;
@@ -269,11 +279,7 @@ __global__ __launch_bounds__(kBlockThreads) void pose_energy_pairs(const PairLau
                     }
                 }
             }
-            // Two atoms on the same spot (d2 = 0, or so small that R^6 / d2^3 overflows): the reference
-            // gets p6 = inf and k = e * (inf - inf) = NaN, which its ordered `k > VDW_CUTOFF` keeps
-            // (src/dna.rs:498-503), so the score is NaN.  fmin/fmax above would turn that NaN into a
-            // clamp value; restore it.
-            if (closest < 1.0e-90) acc1 = __builtin_nan("");
+            if (coincident) acc1 = __builtin_nan("");
         }
         if (lflag && lslot >= 0) atomicOr(&pose_flags[P.rec.flag_words + (lslot >> 5)], 1u << (lslot & 31));
     }

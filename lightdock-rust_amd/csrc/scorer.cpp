@@ -1036,6 +1036,8 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
     if (n == 0) return;
     if (!d_poses || !d_energies) throw Error(LD_ERR_INVALID, "energy_batch: null pose/energy buffer");
     if (stride < pose_len()) throw Error(LD_ERR_INVALID, "energy_batch: stride shorter than a pose row");
+    // the list is the compacted form of the mask: the pair kernels walk the list, the tail kernel the mask
+    if (d_list && (!d_active || !d_count)) throw Error(LD_ERR_INVALID, "energy_batch: a pose list needs its device-side count and the matching active mask");
     if (use_tiled_ && rec_anm_per_pose_) {
         // every pose carries its own deformed receptor image: bound that workspace (8 GiB) by
         // slicing very large batches; poses are independent, so the results do not change

@@ -487,3 +487,16 @@ def test_block_major_cell_lut_decides_like_the_reference(pkg, orc, ubound, exten
     # one flagged cell per bin step and at the cutoff while eps < 1/2 cell; a few more for larger frames
     n_flagged = int((codes == FLAGGED).sum())
     assert 20 <= n_flagged <= 21 * (1 + 2 * int(np.ceil(max(eps - 0.5, 0.0)))) + 2 * int(np.ceil(eps)) + 2      # (the last step is the cutoff)
+
+
+def test_committed_profile_matches_the_kernel_sources():
+    """bench.py reports on-chip counter fractions from profiles/traffic.json: an entry is only valid for the build it
+    was taken from.  The default workload's entry must carry the hash of the kernel sources at HEAD -- change a kernel,
+    re-run tools/profile_round.sh + tools/update_traffic.py (bench.py itself omits stale counters and says so)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    keys = [k for k in t if k.startswith("1k4c:8192:") and t[k].get("source_hash") == bench.kernel_source_hash()]
+    assert keys, "no profiles/traffic.json entry of the default workload carries the hash of the current kernel sources (%s)" % bench.kernel_source_hash()
+    assert any(t[k].get("valu_insts_per_launch") for k in keys)

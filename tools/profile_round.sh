@@ -2,8 +2,8 @@
 #   per workload: --kernel-trace --stats of the bench command (no counters), then separate --pmc passes
 #   (gpurun refuses --pmc combined with tracing domains), then the un-profiled bench line.
 # Usage: bash tools/profile_round.sh <tag> [workload ...]     -> gpurun_out/prof_<tag>/<workload>/
-tag=${1:-r02}; shift
-wls=${@:-1k4c 1azp-dna gso-1ppe}
+tag=${1:-r03}; shift
+wls=${@:-1k4c 1ppe 1azp-dna gso-1ppe gso-1k4c}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for w in $wls; do
   out=gpurun_out/prof_$tag/$w; mkdir -p $out
@@ -19,7 +19,7 @@ FETCH_SIZE
 WRITE_SIZE
 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
-SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA
+SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum
 SETS
   timeout 300 python3 bench.py --workload $w --steps 10 --warmup 3 > $out/bench.json 2> $out/bench.err

@@ -8,7 +8,8 @@ import os
 import sys
 
 out = sys.argv[1]
-KERNELS = ("dfire_packed_pairs<false", "dfire_tiled_pairs<false", "pose_energy_pairs<1", "pose_energy_pairs<0", "gso_movement_phase",
+KERNELS = ("dfire_bm_pairs<false", "dfire_bm_cull<false", "dfire_bm_gather<false", "dfire_bm_pose", "dfire_bm_plan",
+           "dfire_packed_pairs<false", "dfire_tiled_pairs<false", "pose_energy_pairs<1", "pose_energy_pairs<0", "gso_movement_phase",
            "pose_energy_finish", "dfire_packed_prepare")
 
 
@@ -32,8 +33,15 @@ def counters():
 print("== kernel trace (rocprofv3 --kernel-trace --stats) of: bench.py --workload %s --steps 10 --warmup 3" % os.path.basename(out.rstrip("/")))
 for p in glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv")):
     for i, r in enumerate(csv.DictReader(open(p))):
-        if i < 7:
+        if i < 9:
             print("  %-84s calls %5s avg %12.1f ns  %6s %%" % (r["Name"][:84], r["Calls"], float(r["AverageNs"]), r["Percentage"]))
+    # the block-major K1 is five kernels; bench.py's HIP events bracket all of them (`roofline.kernel_ms`)
+    rows = list(csv.DictReader(open(p)))
+    bm = [r for r in rows if "dfire_bm_" in r["Name"] and "<true>" not in r["Name"]]
+    if bm:
+        calls = max(int(r["Calls"]) for r in bm if "pairs" in r["Name"])
+        print("  block-major K1 (pose + cull + plan + pairs + gather), sum of the average durations: %.1f ns over %d launches of the sequence"
+              % (sum(float(r["TotalDurationNs"]) for r in bm) / calls, calls))
 try:
     b = json.load(open(os.path.join(out, "bench_traced.json")))
     print("  bench (traced run): %.0f evals/s, HIP-event kernel_ms %.4f" % (b["value"], b["roofline"]["kernel_ms"]))
@@ -53,6 +61,9 @@ for kern, c in allc.items():
         print("  traffic_json hbm_bytes_per_launch %.0f" % hi)
     if "SQ_INSTS_VALU" in c:
         print("  traffic_json valu_insts_per_launch %.0f" % c["SQ_INSTS_VALU"])
+    if "SQ_ACTIVE_INST_SCA" in c and "SQ_ACTIVE_INST_VALU" in c and "SQ_WAVE_CYCLES" in c:
+        print("  scalar unit busy %.3f, vector unit busy %.3f of the wave cycles; waves waiting %.3f"
+              % (c["SQ_ACTIVE_INST_SCA"] / c["SQ_WAVE_CYCLES"], c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]))
     if "TCC_HIT_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
         print("  L2 hit rate %.4f" % (c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])))
 try:
