@@ -23,7 +23,10 @@ typedef const __attribute__((address_space(4))) BmLaunch BmArgs;
 #define LD_BM_ARGS ((BmArgs *)__builtin_amdgcn_kernarg_segment_ptr())
 
 constexpr int kBmCullWaves = 4;   // independent waves per dfire_bm_cull workgroup
-constexpr int kBmCullPoses = 8;   // poses a wave of dfire_bm_cull walks with its ligand tile
+#ifndef LD_BM_CULL_POSES
+#define LD_BM_CULL_POSES 8
+#endif
+constexpr int kBmCullPoses = LD_BM_CULL_POSES;   // poses a wave of dfire_bm_cull walks with its ligand tile
 constexpr float kBmBoxCut = 14400.0f * 1.00005f;  // (8 * 15 A)^2 in record units, padded for the rounding of the box test
 
 __device__ __forceinline__ uint32_t bm_cvt_u32(float f) {  // v_cvt_u32_f32 saturates: negative and NaN -> 0
@@ -412,8 +415,9 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
     unsigned long long dbg_jobs = 0, dbg_batches = 0, dbg_t_batch = 0, dbg_t_drain = 0, dbg_t_scan = 0, dbg_drains = 0;
 
     for (;;) {
+        const unsigned long long dbg_tj = T->debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
         uint32_t job = 0;
-        if (lane == 0) job = atomicAdd(T->job_next, 1u);
+        if (lane == 0) job = atomicAdd(T->job_next, 1u);   // (drawing one job ahead was measured: the 2048 claimed jobs lengthen the tail)
         job = (uint32_t)__builtin_amdgcn_readfirstlane((int)job);
         if (job >= n_jobs) break;
         const uint32_t jd = job / (uint32_t)kBmJobRows;
@@ -482,8 +486,10 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
         const size_t ent_base = tp * T->cap + lo;
         uint32_t queued = 0;   // wave-uniform
 
+        if (T->debug) dbg_t_scan += __builtin_amdgcn_s_memrealtime() - dbg_tj;   // job set-up
         for (int b = 0; b < 8; b++) {
             if (!((any_bits >> b) & 1u)) continue;
+            const unsigned long long dbg_tblk = T->debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
             {   // stage the block's rows; they land while the entries are scanned
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous block's reads are done
                 const unsigned char *rows = reinterpret_cast<const unsigned char *>(T->m.rows);
@@ -499,18 +505,24 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
             // whose slots are the last two of a row) for the exact path, which sets the flags (src/dfire.rs:339-342).
             const uint32_t flag_from = lig_tracked || __builtin_amdgcn_readlane((int)my_tracked, b) != 0 ? kBmNearCode : kBmFlagged;
             constexpr float seed = (float)kBmCellZero + 0.5f;
-            // ---- the job's entries that hold block (a, b), in entry order
+            // ---- the job's entries that hold block (a, b), in entry order (all 16 chunks' bytes in flight, then the ballots)
             uint32_t n_items = 0;
-            for (int k = 0; k < n_chunks; k++) {
-                const uint32_t bits = WS.row_bits[k * 64 + lane];
-                const bool act = (bits >> b) & 1u;
-                const unsigned long long m = __ballot(act);
-                if (act) {
-                    const uint32_t at = n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    const bool first = (bits & ((1u << b) - 1u)) == 0u;   // the entry's first block of this job (bits hold the job's blocks only): nothing to add to yet
-                    WS.items[at] = (unsigned short)((uint32_t)(k * 64 + lane) | (first ? 0x8000u : 0u));
+            {
+                uint32_t bits16[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) bits16[k] = k < n_chunks ? (uint32_t)WS.row_bits[k * 64 + lane] : 0u;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t bits = bits16[k];
+                    const bool act = (bits >> b) & 1u;
+                    const unsigned long long m = __ballot(act);
+                    if (act) {
+                        const uint32_t at = n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        const bool first = (bits & ((1u << b) - 1u)) == 0u;   // the entry's first block of this job (bits hold the job's blocks only): nothing to add to yet
+                        WS.items[at] = (unsigned short)((uint32_t)(k * 64 + lane) | (first ? 0x8000u : 0u));
+                    }
+                    n_items += (uint32_t)__popcll(m);
                 }
-                n_items += (uint32_t)__popcll(m);
             }
             // receptor subtile b of the tile: 4 pair records, wave-uniform, out of the registers loaded at the job's start
             // The block's distance arithmetic has its origin at the centre c of the receptor subtile's box:
@@ -562,6 +574,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
             };
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the item list as every lane wrote it
             BatchLoads next = issue_loads(0);
+            if (T->debug) dbg_drains += __builtin_amdgcn_s_memrealtime() - dbg_tblk;   // block set-up
             for (uint32_t done = 0; done < n_items; done += 64) {
                 const BatchLoads cur = next;
                 dbg_batches++;
@@ -650,7 +663,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
             const unsigned long long td = T->debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             bm_drain<COUNT>(T, W, WS.queue, queued, lane);
-            if (T->debug) { dbg_t_drain += __builtin_amdgcn_s_memrealtime() - td; dbg_drains++; }
+            if (T->debug) dbg_t_drain += __builtin_amdgcn_s_memrealtime() - td;
         }
     }
     if (T->debug != nullptr && lane == 0) {

@@ -15,8 +15,8 @@ print("jobs per wave mean %.1f (min %d max %d); batches per wave mean %.1f (min 
 print("us per batch (lifetime / batches): mean %.2f" % (life.sum() / batches.sum()))
 h, edges = np.histogram(end, bins=10)
 print("wave end-time histogram (us):", " ".join("%d@%.0f" % (c, e) for c, e in zip(h, edges[1:])))
-print("time in batches: mean %.1f us per wave (%.2f us per batch); in drains: %.1f us per wave, %.1f drains per wave (%.1f us each)" % ((d[:, 4] / 100).mean(), d[:, 4].sum() / 100 / batches.sum(), (d[:, 5] / 100).mean(), d[:, 6].mean(), d[:, 5].sum() / 100 / max(d[:, 6].sum(), 1)))
+print("time in batches: mean %.1f us per wave (%.2f us per batch); in exact-path drains %.1f us; in block set-up %.1f us; in job set-up %.1f us (%.2f us per job)" % ((d[:, 4] / 100).mean(), d[:, 4].sum() / 100 / batches.sum(), (d[:, 5] / 100).mean(), (d[:, 6] / 100).mean(), (d[:, 7] / 100).mean(), d[:, 7].sum() / 100 / max(jobs.sum(), 1)))
 late = end > np.percentile(end, 90)
-print("slowest 10%% of waves: batches %.0f, batch time %.0f us, drain time %.0f us, drains %.1f, jobs %.1f" % (batches[late].mean(), (d[late, 4] / 100).mean(), (d[late, 5] / 100).mean(), d[late, 6].mean(), jobs[late].mean()))
+print("slowest 10%% of waves: batches %.0f, batch time %.0f us, drain time %.0f us, jobs %.1f" % (batches[late].mean(), (d[late, 4] / 100).mean(), (d[late, 5] / 100).mean(), jobs[late].mean()))
 per_cu = batches.reshape(-1, 8).sum(1)
 print("batches per CU: mean %.0f min %d max %d" % (per_cu.mean(), per_cu.min(), per_cu.max()))
