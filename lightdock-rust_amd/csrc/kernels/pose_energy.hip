@@ -234,11 +234,17 @@ __global__ __launch_bounds__(kBlockThreads) void pose_energy_pairs(const PairLau
             }
         } else {
             const double lq = P.lig.charge[la], le = P.lig.well_depth[la], lr = P.lig.radius[la];
-            bool coincident = false;  // a pair whose 12-6 term is NaN in the reference, see below
+            double closest = 1.0;  // smallest d2 seen: (almost) coincident atoms can make the reference's score NaN, see below
             for (int j = j_begin; j < j_end; j++) {
                 const DnaRec a = rec[j];
                 const double dx = a.x - lx, dy = a.y - ly, dz = a.z - lz;
                 const double d2 = dx * dx + dy * dy + dz * dz;  // src/dna.rs:476-478
+                closest = fmin(closest, d2);
+                // (The scalar pipes of this kernel are as busy as the vector pipes -- 0.7 scalar instructions per vector
+                // instruction, the saveexec / cbranch / exec-restore of these nested cutoffs, profiles/r03_1azp_dna_summary.txt --
+                // but they are not what binds it: with the electrostatic term branch-free (select instead of branch: a
+                // third fewer scalar instructions, the reciprocal also for the 34 % of pairs beyond 30 A) the kernel is
+                // 9 % SLOWER, 2.24 against 2.46 M evaluations/s.  The vector pipe decides; the scalar work overlaps.)
                 if (d2 <= kElecCutoff2) {                         // src/dna.rs:481-491
                     // 1/d2 by v_rcp_f64 + one Newton step instead of two correctly rounded f64 divisions.  The ISA
                     // promises v_rcp_f64 only about 2^-24 relative, so one step guarantees about 2^-47 (tens of ulps)
@@ -263,15 +269,6 @@ __global__ __launch_bounds__(kBlockThreads) void pose_energy_pairs(const PairLau
                         double k = vdw_energy * (p6 * p6 - 2.0 * p6);
                         k = fmin(k, kVdwMax);
                         acc1 += k;
-                        // Two atoms on (almost) the same spot: the reference's p6 = R^6 / d2^3 (src/dna.rs:498) is inf when
-                        // d2^3 underflows or the quotient overflows, and k = e * (inf - inf) = NaN, which its ordered
-                        // `k > VDW_CUTOFF` keeps (:499-503): the score is NaN.  A p6 that is huge but finite gives
-                        // k = inf, which it clamps.  fmin above turns both into the clamp value: redo the reference's own
-                        // division for such pairs (none in any real pose) and keep the NaN where it has one.
-                        if (__builtin_expect(d2 < 1.0e-90, 0)) {
-                            const double p6_ref = rr6 / (d2 * (d2 * d2));
-                            if (!(p6_ref <= 1.7976931348623157e308)) coincident = true;
-                        }
                         if (d2 <= P.iface_d2) {  // src/dna.rs:507-510
                             if (a.slot >= 0) atomicOr(&pose_flags[a.slot >> 5], 1u << (a.slot & 31));
                             lflag = true;
@@ -279,7 +276,23 @@ __global__ __launch_bounds__(kBlockThreads) void pose_energy_pairs(const PairLau
                     }
                 }
             }
-            if (coincident) acc1 = __builtin_nan("");
+            // Two atoms on (almost) the same spot: the reference's p6 = R^6 / d2^3 (src/dna.rs:498) is inf when d2^3
+            // underflows or the quotient overflows, and k = e * (inf - inf) = NaN, which its ordered `k > VDW_CUTOFF`
+            // keeps (:499-503): the score is NaN.  A p6 that is huge but finite gives k = inf, which it clamps.  fmin
+            // above turns both into the clamp value: for such a lane (none in any real pose) redo the reference's own
+            // division and keep the NaN where it has one.
+            if (__builtin_expect(closest < 1.0e-90, 0)) {
+                for (int j = j_begin; j < j_end; j++) {
+                    const DnaRec a = rec[j];
+                    const double dx = a.x - lx, dy = a.y - ly, dz = a.z - lz;
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    if (!(d2 < 1.0e-90)) continue;
+                    const double rr = a.radius + lr;
+                    const double rr2 = rr * rr;
+                    const double p6_ref = (rr2 * (rr2 * rr2)) / (d2 * (d2 * d2));
+                    if (!(p6_ref <= 1.7976931348623157e308)) acc1 = __builtin_nan("");
+                }
+            }
         }
         if (lflag && lslot >= 0) atomicOr(&pose_flags[P.rec.flag_words + (lslot >> 5)], 1u << (lslot & 31));
     }
