@@ -166,6 +166,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     const int la = lt * 64 + lane;
     const float4 loc = reinterpret_cast<const float4 *>(T->m.lig_local)[la];
     const bool valid = loc.w != 0.f;
+    const float4 sphere = reinterpret_cast<const float4 *>(T->m.lig_tile_sphere)[lt];
     // this lane's receptor tile box (the first 64 tiles; larger receptors load the rest per pose)
     TiledBox my_tile = TiledBox{INFINITY, INFINITY, INFINITY, 0.f, -INFINITY, -INFINITY, -INFINITY, 0.f};
     if (lane < n_rt) my_tile = T->m.rec_tile[lane];
@@ -180,6 +181,19 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         if (pose_of[g] < 0) continue;
         const size_t pose = (size_t)pose_of[g];
         const Affine A = bm_load_affine(T->rt, pose);
+        {   // a tile whose bounding sphere stays beyond the cutoff of the receptor's box has nothing to list (most tiles
+            // of a large ligand, in most poses): one point posed instead of 64 atoms, boxes and tile tests
+            float sx, sy, sz;
+            bm_apply(A, sphere.x, sphere.y, sphere.z, sx, sy, sz);
+            const float gx = fmaxf(0.f, fmaxf(T->m.rec_lo[0] - sx, sx - T->m.rec_hi[0]));
+            const float gy = fmaxf(0.f, fmaxf(T->m.rec_lo[1] - sy, sy - T->m.rec_hi[1]));
+            const float gz = fmaxf(0.f, fmaxf(T->m.rec_lo[2] - sz, sz - T->m.rec_hi[2]));
+            const float reach = 120.0f * 1.0001f + sphere.w + pad;   // (8 * 15 A, the sphere's radius, the affine map's error)
+            if (gx * gx + gy * gy + gz * gz > reach * reach) {
+                if (COUNT && lane == 0) T->tile_tested[pose * (size_t)n_lt + lt] = 0;
+                continue;
+            }
+        }
         float fx, fy, fz;
         bm_apply(A, loc.x, loc.y, loc.z, fx, fy, fz);
         const bool inside = fabsf(fx) <= ubound && fabsf(fy) <= ubound && fabsf(fz) <= ubound;
@@ -632,23 +646,35 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                     }
                     asm volatile("" : "+v"(acc));   // the group's adds end here (the scheduler would park table values in registers)
                     if (__builtin_expect(__ballot(wm >= flag_from) != 0ull, 0)) {
-                        // pairs in flagged cells read 0.0 above; queue them for the exact path
-                        uint32_t el_here = el;
-                        asm volatile("" : "+v"(el_here));   // (keep the compiler from preparing any of this outside the branch)
+                        // Pairs in flagged cells read 0.0 above; queue them for the exact path.  Most groups of a 1k4c
+                        // batch come here for one or two of their 1024 pairs, so the way in is vector-only: every lane
+                        // turns its 16 codes into a bit mask (no scalar compare-and-branch per code: 16 of those cost four
+                        // times the group's arithmetic), then the few lanes with a bit set push one pair per round.
+                        uint32_t fm = 0, fm_only = 0;   // bit k: pair k of the group goes to the exact path / for its flags only
 #pragma unroll
-                        for (int k = 0; k < 16; k++) {
-                            const bool f = valid && w[k] >= flag_from;
-                            const unsigned long long m = __ballot(f);
-                            if (m == 0ull) continue;
+                        for (int k = 0; k < 16; k++) fm |= (w[k] >= flag_from ? 1u : 0u) << k;
+                        if (flag_from != kBmFlagged) {   // a block with tracked atoms (wave-uniform, rare)
+#pragma unroll
+                            for (int k = 0; k < 16; k++) fm_only |= (w[k] < kBmFlagged ? 1u : 0u) << k;
+                        }
+                        if (!valid) fm = 0;
+                        unsigned long long live = __ballot(fm != 0u);
+                        while (live != 0ull) {
                             if (queued > (uint32_t)kBmQueue - 64u) {   // room for 64 more, always: a pose's sum never depends on its batch
                                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                                 bm_drain<COUNT>(T, W, WS.queue, queued, lane);
                                 queued = 0;
                             }
-                            const int t = g * 8 + (k >> 1), q = t / kBmLig, i = t % kBmLig;
-                            const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                            if (f) WS.queue[at] = el_here | (uint32_t)((la0 + i) * 8 + 2 * q + (k & 1)) << 10 | (uint32_t)b << 16 | (w[k] < kBmFlagged ? kBmFlagsOnly : 0u);
-                            queued += (uint32_t)__popcll(m);
+                            const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+                            if (fm != 0u) {
+                                const uint32_t k = (uint32_t)__builtin_ctz(fm);
+                                const uint32_t t = (uint32_t)g * 8u + (k >> 1), q = t / (uint32_t)kBmLig, i = t % (uint32_t)kBmLig;   // the step, its pair k & 1
+                                WS.queue[at] = el | (((uint32_t)la0 + i) * 8u + 2u * q + (k & 1u)) << 10 | (uint32_t)b << 16 |
+                                               ((fm_only >> k) & 1u ? kBmFlagsOnly : 0u);
+                                fm &= fm - 1u;
+                            }
+                            queued += (uint32_t)__popcll(live);
+                            live = __ballot(fm != 0u);
                         }
                     }
                 }
@@ -689,10 +715,11 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
     __shared__ uint32_t s_cnt[512], s_tested[512];
     const int tid = threadIdx.x;
     const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
-    // a workgroup holds 512 / span poses, span = the power of two that covers a pose's (ligand tile, partial-sum row) pairs
-    const int rows = n_lt * kBmJobRows;
-    int span = kBmJobRows;
-    while (span < rows && span < 512) span <<= 1;
+    // thread = (pose, ligand tile); a workgroup holds 512 / span poses, span = the power of two that covers the ligand's
+    // tiles.  The kernel is bound by the latency of three dependent loads per entry: many poses in flight per CU, and
+    // per thread the partial sums of four entries x all their rows requested together.
+    int span = 1;
+    while (span < n_lt && span < 512) span <<= 1;
     const int per_wg = 512 / span, sub = tid / span, r0 = tid % span;
     const size_t n_rows = bm_rows(T);
     for (size_t first_row = (size_t)blockIdx.x * per_wg; first_row < n_rows; first_row += (size_t)gridDim.x * per_wg) {
@@ -701,33 +728,35 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
     const size_t pose = pp < 0 ? 0 : (size_t)pp;
     double s = 0.0;
     uint32_t cnt = 0, tested = 0;
-    for (int r = r0; pp >= 0 && r < rows; r += span) {   // thread = (ligand tile, partial-sum row): its entries in the order the culling listed them
-        const int lt = r / kBmJobRows, jrow = r % kBmJobRows;
-        const int sub_half = jrow / (kBmSplit * kBmHalves) * kBmHalves + jrow % kBmHalves;   // (ligand subtile, part of its blocks)
+    for (int lt = r0; pp >= 0 && lt < n_lt; lt += span) {   // the tile's entries in the order the culling listed them, their rows in order
         const size_t slot = pose * (size_t)n_lt + lt;
-        if (COUNT && jrow == 0) tested += T->tile_tested[slot];
+        if (COUNT) tested += T->tile_tested[slot];
         const uint32_t n_vis = T->vis_count[slot];
-        for (uint32_t v0 = 0; v0 < n_vis; v0 += 4) {   // four entries in flight (the loop is bound by the two dependent loads)
+        for (uint32_t v0 = 0; v0 < n_vis; v0 += 4) {
             unsigned long long ent[4];
-            double part[4];
-            uint32_t pc[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) ent[k] = v0 + k < n_vis ? T->vis_entry[slot * (size_t)n_rt + v0 + k] : 0ull;
+            double part[4][kBmJobRows];
+            uint32_t pc[4][kBmJobRows];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                part[k] = 0.0;
-                pc[k] = 0;
-                if (!((ent[k] >> (32 + sub_half)) & 1ull)) continue;
                 const size_t tp = (size_t)lt * n_rt + (size_t)(ent[k] >> 48);
-                const size_t pslot = (tp * kBmJobRows + (size_t)jrow) * T->cap + (size_t)(ent[k] & 0xffffffffull);
-                part[k] = T->ent_partial[pslot];
-                if (COUNT) pc[k] = T->ent_count[pslot];
+                const size_t at = tp * kBmJobRows * T->cap + (size_t)(ent[k] & 0xffffffffull);
+#pragma unroll
+                for (int jrow = 0; jrow < kBmJobRows; jrow++) {
+                    const int sub_half = jrow / (kBmSplit * kBmHalves) * kBmHalves + jrow % kBmHalves;   // (ligand subtile, part of its blocks)
+                    const bool on = (ent[k] >> (32 + sub_half)) & 1ull;
+                    part[k][jrow] = on ? T->ent_partial[at + (size_t)jrow * T->cap] : 0.0;
+                    pc[k][jrow] = COUNT && on ? T->ent_count[at + (size_t)jrow * T->cap] : 0u;
+                }
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                s += part[k];   // (an entry without a block in this row adds 0.0: no bit of the sum changes)
-                cnt += pc[k];
-            }
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int jrow = 0; jrow < kBmJobRows; jrow++) {
+                    s += part[k][jrow];   // (a row without a block of the entry adds 0.0: no bit of the sum changes)
+                    cnt += pc[k][jrow];
+                }
         }
     }
     s_sum[tid] = s;
@@ -791,9 +820,8 @@ hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
 
 hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    const int rows = t.m.lig.n_tiles * kBmJobRows;
-    int span = kBmJobRows;
-    while (span < rows && span < 512) span <<= 1;
+    int span = 1;
+    while (span < t.m.lig.n_tiles && span < 512) span <<= 1;
     const size_t per_wg = 512 / span;
     const unsigned blocks = (unsigned)std::min<size_t>((t.n_poses + per_wg - 1) / per_wg, 16384);
     if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_gather<true>), dim3(blocks), dim3(512), 0, stream, t);

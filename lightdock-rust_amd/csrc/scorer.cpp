@@ -803,6 +803,40 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
             local[4 * i + 3] = 1.f;
         }
         M.lig_local = arena_.upload(local);
+        // a sphere around every ligand tile (rotation invariant): centre of its box, radius to its farthest atom
+        std::vector<float> sphere((size_t)lig.n_tiles * 4, 0.f);
+        for (int t = 0; t < lig.n_tiles; t++) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (int i = t * 64; i < t * 64 + 64; i++) {
+                if (lig.htype[i] == kPad) continue;
+                const double c[3] = {lig.hx[i], lig.hy[i], lig.hz[i]};
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = std::min(lo[k], c[k]);
+                    hi[k] = std::max(hi[k], c[k]);
+                }
+            }
+            float ctr[3];
+            for (int k = 0; k < 3; k++) ctr[k] = lo[k] <= hi[k] ? (float)(0.5 * (lo[k] + hi[k])) : 0.f;
+            double r = 0.0;
+            for (int i = t * 64; i < t * 64 + 64; i++) {
+                if (lig.htype[i] == kPad) continue;
+                const double dx = lig.hx[i] - ctr[0], dy = lig.hy[i] - ctr[1], dz = lig.hz[i] - ctr[2];
+                r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz));
+            }
+            for (int k = 0; k < 3; k++) sphere[4 * t + k] = ctr[k];
+            sphere[4 * t + 3] = std::nextafter((float)(kBmKappa * r * 1.000001 + 1e-3), INFINITY);
+        }
+        M.lig_tile_sphere = arena_.upload(sphere);
+        double rlo[3] = {1e300, 1e300, 1e300}, rhi[3] = {-1e300, -1e300, -1e300};
+        for (size_t i = 0; i < desc.receptor.n_atoms; i++)
+            for (int k = 0; k < 3; k++) {
+                rlo[k] = std::min(rlo[k], desc.receptor.coordinates[3 * i + k]);
+                rhi[k] = std::max(rhi[k], desc.receptor.coordinates[3 * i + k]);
+            }
+        for (int k = 0; k < 3; k++) {   // record units, rounded outwards
+            M.rec_lo[k] = std::nextafter((float)(kBmKappa * (rlo[k] - centre[k]) - 1e-3), -INFINITY);
+            M.rec_hi[k] = std::nextafter((float)(kBmKappa * (rhi[k] - centre[k]) + 1e-3), INFINITY);
+        }
     }
     {   // rows[l][r][0] = 0.0; rows[l][r][bm_slot_of_bin(b)] = potential[r * 3380 + l * 20 + b], b = 0..20 (20 = the read past the row, src/dfire.rs:338)
         std::vector<double> rows((size_t)kBmTypes * kBmTypes * kBmRowSlots, 0.0);
