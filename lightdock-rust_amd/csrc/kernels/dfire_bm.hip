@@ -650,12 +650,14 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                         // batch come here for one or two of their 1024 pairs, so the way in is vector-only: every lane
                         // turns its 16 codes into a bit mask (no scalar compare-and-branch per code: 16 of those cost four
                         // times the group's arithmetic), then the few lanes with a bit set push one pair per round.
+                        // (two operations per code and no compare: the sign of code - threshold shifted in by v_alignbit_b32)
                         uint32_t fm = 0, fm_only = 0;   // bit k: pair k of the group goes to the exact path / for its flags only
 #pragma unroll
-                        for (int k = 0; k < 16; k++) fm |= (w[k] >= flag_from ? 1u : 0u) << k;
+                        for (int k = 15; k >= 0; k--) fm = __builtin_amdgcn_alignbit(fm, w[k] - flag_from, 31);   // fm << 1 | (code below the threshold)
+                        fm = ~fm & 0xffffu;
                         if (flag_from != kBmFlagged) {   // a block with tracked atoms (wave-uniform, rare)
 #pragma unroll
-                            for (int k = 0; k < 16; k++) fm_only |= (w[k] < kBmFlagged ? 1u : 0u) << k;
+                            for (int k = 15; k >= 0; k--) fm_only = __builtin_amdgcn_alignbit(fm_only, w[k] - kBmFlagged, 31);
                         }
                         if (!valid) fm = 0;
                         unsigned long long live = __ballot(fm != 0u);
