@@ -359,6 +359,92 @@ __global__ __launch_bounds__(1024) void dfire_bm_plan(const BmLaunch launch_argu
 }
 
 // ---------------------------------------------------------------------------------------------
+// dfire_bm_order: how long is each job, and in which order should the waves of dfire_bm_pairs draw them?  A job's length
+// is set by the block bits of its entries (16 on average of the 64 a mask has room for, between 0 and 8 in a row), not
+// by the number of entries: jobs of equal entry count differ eightfold.  Every wave takes (tile pair, part) pairs, counts
+// per row the block bits of the part's entries and the distinct blocks, and writes an estimate in units of 1/64 batch:
+//   items + 96 per block present (staging, the last batch's empty lanes) + 224 (job set-up)
+// The workgroup that finishes last then lists the jobs that have any work by class of estimated length, longest first
+// (counting sort in LDS): the launch ends on jobs of a few batches, and rows without a block are never drawn.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBmOrderWaves = 16;
+__global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_order(const BmLaunch launch_arguments) {
+    static_assert(kBmJobRows == 8 && kBmHalves == 1 && kBmSplit == 1, "a job row is one byte of the block mask");
+    BmArgs *T = LD_BM_ARGS;
+    __shared__ uint32_t s_class[kBmCostClasses];
+    __shared__ uint32_t s_last;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t n_pairs = T->job_count[0], P = T->job_count[2];
+    for (uint32_t jd = blockIdx.x * kBmOrderWaves + wave; jd < n_pairs; jd += gridDim.x * kBmOrderWaves) {
+        const size_t tp = T->jobs[2 * jd];
+        const uint32_t lo = T->jobs[2 * jd + 1];
+        const uint32_t n = T->tp_count[tp];
+        const uint32_t hi = n < lo + P ? n : lo + P;
+        unsigned long long m[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t e = lo + (uint32_t)k * 64 + lane;
+            m[k] = e < hi ? T->ent_mask[tp * T->cap + e] : 0ull;
+        }
+        uint32_t items[8], present_lo = 0, present_hi = 0;   // per row; the OR of the masks
+#pragma unroll
+        for (int r = 0; r < 8; r++) items[r] = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            present_lo |= (uint32_t)m[k];
+            present_hi |= (uint32_t)(m[k] >> 32);
+#pragma unroll
+            for (int r = 0; r < 8; r++) items[r] += (uint32_t)__popc((uint32_t)(m[k] >> (8 * r)) & 0xffu);
+        }
+        // sums over the wave: two rows to a word (each below 2^14)
+        uint32_t pk[4] = {items[0] | items[1] << 16, items[2] | items[3] << 16, items[4] | items[5] << 16, items[6] | items[7] << 16};
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) pk[q] += (uint32_t)__shfl_xor((int)pk[q], off, 64);
+            present_lo |= (uint32_t)__shfl_xor((int)present_lo, off, 64);
+            present_hi |= (uint32_t)__shfl_xor((int)present_hi, off, 64);
+        }
+        if (lane < 8) {
+            const uint32_t word = lane < 2 ? pk[0] : lane < 4 ? pk[1] : lane < 6 ? pk[2] : pk[3];
+            const uint32_t it = (lane & 1) ? word >> 16 : word & 0xffffu;
+            const uint32_t blocks = (uint32_t)__popc(((lane < 4 ? present_lo : present_hi) >> (8 * (lane & 3))) & 0xffu);
+            T->job_cost[(size_t)jd * kBmJobRows + lane] = it ? it + 96u * blocks + 224u : 0u;
+        }
+    }
+    // the last workgroup to get here orders the jobs
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(T->job_count + 4, 1u) == gridDim.x - 1 ? 1u : 0u;
+    for (int c = tid; c < kBmCostClasses; c += kBmOrderWaves * 64) s_class[c] = 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const uint32_t n_jobs = n_pairs * (uint32_t)kBmJobRows;
+    auto class_of = [](uint32_t cost) { const uint32_t c = cost >> 7; return c < (uint32_t)kBmCostClasses ? c : (uint32_t)kBmCostClasses - 1u; };
+    for (uint32_t j = tid; j < n_jobs; j += kBmOrderWaves * 64) {
+        const uint32_t cost = __builtin_nontemporal_load(T->job_cost + j);
+        if (cost) atomicAdd(&s_class[class_of(cost)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t at = 0;
+        for (int c = kBmCostClasses - 1; c >= 0; c--) {
+            const uint32_t k = s_class[c];
+            s_class[c] = at;
+            at += k;
+        }
+        T->job_count[3] = at;
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < n_jobs; j += kBmOrderWaves * 64) {
+        const uint32_t cost = __builtin_nontemporal_load(T->job_cost + j);
+        if (cost) T->job_order[atomicAdd(&s_class[class_of(cost)], 1u)] = j;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // dfire_bm_pairs: persistent workgroups (one per CU) of 8 independent waves; a wave draws jobs
 // (tile pair, part of its entries, ligand subtile a) and walks the job's 8 blocks (a, b), each with its 64 table
 // rows staged in the wave's own slice of LDS.  The waves share the cell LUT and nothing else: no barrier after set-up.
@@ -424,7 +510,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
     if (lane < 4) reinterpret_cast<uint32_t *>(WS.cube + kBmCubeRows * kBmRowBytes)[lane] = 0u;   // the zero slot behind the last row
     __syncthreads();
     const unsigned char *cube = WS.cube;
-    const uint32_t n_jobs = T->job_count[0] * (uint32_t)kBmJobRows, part_entries = T->job_count[2];
+    const uint32_t n_jobs = T->job_count[3], part_entries = T->job_count[2];
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long dbg_jobs = 0, dbg_batches = 0, dbg_t_batch = 0, dbg_t_drain = 0, dbg_t_scan = 0, dbg_drains = 0;
 
@@ -434,6 +520,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
         if (lane == 0) job = atomicAdd(T->job_next, 1u);   // (drawing one job ahead was measured: the 2048 claimed jobs lengthen the tail)
         job = (uint32_t)__builtin_amdgcn_readfirstlane((int)job);
         if (job >= n_jobs) break;
+        job = T->job_order[job];   // longest first (dfire_bm_order)
         const uint32_t jd = job / (uint32_t)kBmJobRows;
         const int jrow = (int)(job % (uint32_t)kBmJobRows);   // partial-sum row of the entry: (job row of the tile, part of its blocks)
         const int arow = jrow / kBmHalves, b_lo = (jrow % kBmHalves) * (8 / kBmHalves);
@@ -512,7 +599,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                     const int row = (t * 64 + lane) / 11;
                     const uint32_t roff = (uint32_t)__shfl((int)roff_all, b * 8 + (row & 7), 64);
                     if (t * 64 + 63 < kPieces || t * 64 + lane < kPieces)   // (the last KiB may be partial)
-                        __builtin_amdgcn_global_load_lds((const global_u32 *)(rows + src_lig[t] + roff), (lds_u32 *)(WS.cube + t * 1024), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((const global_u32 *)(rows + (src_lig[t] + roff)), (lds_u32 *)(WS.cube + t * 1024), 16, 0, 0);
                 }
             }
             // A block with an atom that has an interface-flag slot also queues its pairs closer than 2.5 A (bins 0 and 1,
@@ -600,11 +687,13 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                 const bool valid = lane < count;
                 const uint32_t el = cur.item & 0x7fffu;
                 const Affine A{cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w - cbx, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w - cby, cur.a2.x, cur.a2.y, cur.a2.z, cur.a2.w - cbz};
-                float lx[kBmLig], ly[kBmLig], lz[kBmLig], l2[kBmLig];   // l - c and |l - c|^2
+                v2f lxy[kBmLig], lz2[kBmLig];   // l - c as {x, y} and {z, |l - c|^2}: the packed operations broadcast either half (op_sel)
 #pragma unroll
                 for (int i = 0; i < kBmLig; i++) {
-                    bm_apply(A, Lx[i], Ly[i], Lz[i], lx[i], ly[i], lz[i]);
-                    l2[i] = __builtin_fmaf(lx[i], lx[i], __builtin_fmaf(ly[i], ly[i], lz[i] * lz[i]));
+                    float lx, ly, lz;
+                    bm_apply(A, Lx[i], Ly[i], Lz[i], lx, ly, lz);
+                    lxy[i] = v2f{lx, ly};
+                    lz2[i] = v2f{lz, __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz))};
                 }
                 double acc = 0.0;
                 uint32_t cnt = 0;
@@ -612,20 +701,28 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                 // codes, all table values of a group in flight, then the adds in order and one test for flagged cells.
                 // Step t of the batch: q = t / kBmLig, i = t % kBmLig.
                 constexpr int kGroups = kBmLig / 2;
-#pragma unroll
-                for (int g = 0; g < kGroups; g++) {
-                    uint32_t w[16];
+                auto codes_of_group = [&](int g, uint32_t (&w)[16]) {
 #pragma unroll
                     for (int s8 = 0; s8 < 8; s8++) {
                         const int t = g * 8 + s8, q = t / kBmLig, i = t % kBmLig;
-                        v2f D = Rs[q] - v2f{l2[i], l2[i]};
-                        D = __builtin_elementwise_fma(Rz[q], v2f{lz[i], lz[i]}, D);
-                        D = __builtin_elementwise_fma(Ry[q], v2f{ly[i], ly[i]}, D);
-                        D = __builtin_elementwise_fma(Rx[q], v2f{lx[i], lx[i]}, D);
+                        // D = Rs - l2; D = fma(Rz, lz, D); D = fma(Ry, ly, D); D = fma(Rx, lx, D), both halves: written out
+                        // because the compiler duplicates the broadcast operands into register pairs (32 moves a group)
+                        v2f D;
+                        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(D) : "v"(Rs[q]), "v"(lz2[i]));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(D) : "v"(Rz[q]), "v"(lz2[i]));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(D) : "v"(Ry[q]), "v"(lxy[i]));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(D) : "v"(Rx[q]), "v"(lxy[i]));
                         const uint32_t c0 = bm_cvt_u32(D.x), c1 = bm_cvt_u32(D.y);
                         w[2 * s8] = S.lut[c0];
                         w[2 * s8 + 1] = S.lut[c1];
                     }
+                };
+                // (computing the codes of group g + 1 while the table values of group g are on their way was tried: the second
+                // wave of the SIMD already fills those waits, and the 16 extra live registers spill the block set-up)
+#pragma unroll
+                for (int g = 0; g < kGroups; g++) {
+                    uint32_t w[16];
+                    codes_of_group(g, w);
 #pragma unroll
                     for (int k = 0; k < 16; k++) asm("" : "+v"(w[k]));   // 32-bit values from here on (no 16-bit detours on the way to the address)
                     double tv[16];
@@ -814,6 +911,7 @@ hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream) {
 hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
     hipLaunchKernelGGL(dfire_bm_plan, dim3(1), dim3(1024), 0, stream, t);
+    hipLaunchKernelGGL(dfire_bm_order, dim3(128), dim3(kBmOrderWaves * 64), 0, stream, t);
     const unsigned groups = t.pairs_groups > 0 ? (unsigned)t.pairs_groups : 256u;   // persistent: one workgroup per CU
     if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_pairs<true>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
     else hipLaunchKernelGGL((dfire_bm_pairs<false>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);

@@ -66,6 +66,9 @@ constexpr int kBmWaves = kBmLig == 4 ? 12 : LD_BM_WAVES;  // waves per dfire_bm_
 constexpr int kBmPartEntries = 1024;         // entries of a tile pair in one job
 constexpr int kBmQueue = 128;                // per wave: pairs waiting for the exact path
 constexpr double kBmFixScale = 1099511627776.0;  // 2^40: fixed-point units of the exact path's sum
+constexpr int kBmCounters = 8;               // words behind tp_count, zeroed per launch: (tile pair, part) pairs listed, jobs drawn, entries per
+                                             // part, jobs listed, workgroups of dfire_bm_order done
+constexpr int kBmCostClasses = 80;           // jobs are drawn in classes of estimated length, longest first
 
 struct BmModel {
     // receptor (static image in the kappa = 8 frame; no receptor ANM on this path)
@@ -118,8 +121,11 @@ struct BmLaunch {
     double *ent_partial = nullptr;         // [tile pair][kBmJobRows][cap]
     uint32_t *ent_count = nullptr;         // [tile pair][kBmJobRows][cap] or nullptr (counting launches)
     uint32_t *jobs = nullptr;              // [(tile pair, part)][2]: tile pair, first entry; written by dfire_bm_plan
-    uint32_t *job_count = nullptr;         // [4], zeroed per launch: (tile pair, part) pairs listed, jobs drawn (job_next = job_count + 1), entries per part
+    uint32_t *job_count = nullptr;         // [kBmCounters], zeroed per launch: (tile pair, part) pairs listed, jobs drawn (job_next = job_count + 1),
+                                           // entries per part, jobs listed in job_order, workgroups of dfire_bm_order done
     uint32_t *job_next = nullptr;
+    uint32_t *job_cost = nullptr;          // [(tile pair, part)][kBmJobRows]: estimated length of the job (0: no block of that row in any entry)
+    uint32_t *job_order = nullptr;         // the jobs ((tile pair, part) index * kBmJobRows + row) that have work, longest first
     int pairs_groups = 0;                  // workgroups of dfire_bm_pairs (0: one per CU of an MI355X)
     unsigned long long *debug = nullptr;   // diagnostics (LIGHTDOCK_BM_DEBUG): per wave of dfire_bm_pairs {start, end (100 MHz), jobs, batches}
     uint32_t *vis_count = nullptr;         // [pose][lig tiles]

@@ -922,16 +922,18 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         const size_t w = (size_t)lane;   // workspace set
         t.first = off;
         t.n_poses = std::min(cap, n - off);
-        t.tp_count = static_cast<uint32_t *>(ws_bm_tp_count_.ptr) + w * (tile_pairs + 4);
+        t.tp_count = static_cast<uint32_t *>(ws_bm_tp_count_.ptr) + w * (tile_pairs + kBmCounters);
         t.job_count = t.tp_count + tile_pairs;
         t.job_next = t.tp_count + tile_pairs + 1;
         t.jobs = static_cast<uint32_t *>(ws_bm_jobs_.ptr) + w * jobs_per_lane;
+        t.job_cost = static_cast<uint32_t *>(ws_bm_job_cost_.ptr) + w * jobs_per_lane / 2 * kBmJobRows;
+        t.job_order = static_cast<uint32_t *>(ws_bm_job_order_.ptr) + w * jobs_per_lane / 2 * kBmJobRows;
         t.ent_pose = static_cast<uint32_t *>(ws_bm_ent_pose_.ptr) + w * tile_pairs * cap;
         t.ent_mask = static_cast<unsigned long long *>(ws_bm_ent_mask_.ptr) + w * tile_pairs * cap;
         t.ent_rt = static_cast<float *>(ws_bm_ent_rt_.ptr) + w * tile_pairs * cap * 12;
         t.ent_partial = static_cast<double *>(ws_bm_ent_partial_.ptr) + w * tile_pairs * kBmJobRows * cap;
         t.ent_count = counts ? static_cast<uint32_t *>(ws_bm_ent_count_.ptr) + w * tile_pairs * kBmJobRows * cap : nullptr;
-        hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + 4) * sizeof(uint32_t), st), "hipMemsetAsync(tile pair counts)");
+        hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + kBmCounters) * sizeof(uint32_t), st), "hipMemsetAsync(tile pair counts)");
         hip_check(launch_bm_pose(t, st), "launch dfire_bm_pose");
         hip_check(launch_bm_cull(t, st), "launch dfire_bm_cull");
         hip_check(launch_bm_pairs(t, st), "launch dfire_bm_pairs");
@@ -1018,7 +1020,7 @@ Scorer::~Scorer() {
     ws_rec_tile_.release();
     ws_rec_pairs_.release();
     ws_exact_.release();
-    for (DeviceBuffer *b : {&ws_bm_rt_, &ws_bm_tp_count_, &ws_bm_ent_pose_, &ws_bm_jobs_, &ws_bm_ent_mask_, &ws_bm_ent_rt_, &ws_bm_ent_partial_, &ws_bm_ent_count_, &ws_bm_vis_count_,
+    for (DeviceBuffer *b : {&ws_bm_rt_, &ws_bm_tp_count_, &ws_bm_ent_pose_, &ws_bm_jobs_, &ws_bm_job_cost_, &ws_bm_job_order_, &ws_bm_ent_mask_, &ws_bm_ent_rt_, &ws_bm_ent_partial_, &ws_bm_ent_count_, &ws_bm_vis_count_,
                             &ws_bm_vis_entry_, &ws_bm_tile_tested_, &ws_bm_exact_fix_, &ws_bm_exact_count_, &ws_bm_exact_pairs_})
         b->release();
     ws_poses_.release();
@@ -1028,7 +1030,7 @@ Scorer::~Scorer() {
 uint64_t Scorer::workspace_generation() const {
     return ws_partial_.generation + ws_flags_.generation + ws_counts_.generation + ws_tested_.generation + ws_exact_.generation +
            ws_rec_atoms_.generation + ws_rec_sub_.generation + ws_rec_tile_.generation + ws_rec_pairs_.generation + ws_bm_rt_.generation +
-           ws_bm_tp_count_.generation + ws_bm_ent_pose_.generation + ws_bm_jobs_.generation + ws_bm_ent_mask_.generation + ws_bm_ent_rt_.generation + ws_bm_ent_partial_.generation +
+           ws_bm_tp_count_.generation + ws_bm_ent_pose_.generation + ws_bm_jobs_.generation + ws_bm_job_cost_.generation + ws_bm_job_order_.generation + ws_bm_ent_mask_.generation + ws_bm_ent_rt_.generation + ws_bm_ent_partial_.generation +
            ws_bm_ent_count_.generation + ws_bm_vis_count_.generation + ws_bm_vis_entry_.generation + ws_bm_tile_tested_.generation +
            ws_bm_exact_fix_.generation + ws_bm_exact_count_.generation + ws_bm_exact_pairs_.generation;
 }
@@ -1047,8 +1049,10 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         const size_t n = n_poses, n_lt = (size_t)bm_.lig.n_tiles, n_rt = (size_t)bm_.rec_n_tiles, tile_pairs = n_lt * n_rt;
         const size_t cap = bm_pass_poses(n) * 2;   // two passes in flight (run_bm), each with its own entry workspace
         ws_bm_rt_.reserve(n * 12 * sizeof(float));
-        ws_bm_tp_count_.reserve(2 * (tile_pairs + 4) * sizeof(uint32_t));   // + parts listed, jobs drawn, entries per part
+        ws_bm_tp_count_.reserve(2 * (tile_pairs + kBmCounters) * sizeof(uint32_t));   // + the launch's counters
         ws_bm_jobs_.reserve(2 * (tile_pairs * (cap / 2 / 64 + 1)) * 2 * sizeof(uint32_t));   // at most entries / 64 + tile pairs parts
+        ws_bm_job_cost_.reserve(2 * (tile_pairs * (cap / 2 / 64 + 1)) * kBmJobRows * sizeof(uint32_t));
+        ws_bm_job_order_.reserve(2 * (tile_pairs * (cap / 2 / 64 + 1)) * kBmJobRows * sizeof(uint32_t));
         ws_bm_ent_pose_.reserve(tile_pairs * cap * sizeof(uint32_t));
         ws_bm_ent_mask_.reserve(tile_pairs * cap * sizeof(unsigned long long));
         ws_bm_ent_rt_.reserve(tile_pairs * cap * 12 * sizeof(float));
