@@ -22,11 +22,28 @@ namespace {
 typedef const __attribute__((address_space(4))) BmLaunch BmArgs;
 #define LD_BM_ARGS ((BmArgs *)__builtin_amdgcn_kernarg_segment_ptr())
 
-constexpr int kBmCullWaves = 4;   // independent waves per dfire_bm_cull workgroup
+#ifndef LD_BM_CULL_WAVES
+#define LD_BM_CULL_WAVES 4
+#endif
+constexpr int kBmCullWaves = LD_BM_CULL_WAVES;   // independent waves per dfire_bm_cull workgroup
 #ifndef LD_BM_CULL_POSES
 #define LD_BM_CULL_POSES 8
 #endif
 constexpr int kBmCullPoses = LD_BM_CULL_POSES;   // poses a wave of dfire_bm_cull walks with its ligand tile
+constexpr int kBmCullHitTiles = 4;              // hit list of a dfire_bm_cull wave: room for this many poses that reach every receptor tile
+__host__ __device__ inline int bm_cull_hit_cap(int n_rt) { return kBmCullHitTiles * n_rt > 192 ? kBmCullHitTiles * n_rt : 192; }   // (a flush costs one atomic per tile pair)
+__host__ __device__ inline size_t bm_cull_wave_lds(int n_rt) { return ((size_t)bm_cull_hit_cap(n_rt) * 12 + (size_t)n_rt * 8 + 15) / 16 * 16; }
+// dfire_bm_gather: threads per pose = span (a power of two covering the ligand's tiles) x chunks (up to 64 threads per pose)
+__host__ __device__ inline int bm_gather_span(int n_lt) {
+    int span = 1;
+    while (span < n_lt && span < 512) span <<= 1;
+    return span;
+}
+__host__ __device__ inline int bm_gather_chunks(int n_lt, int n_rt) {
+    int chunks = 1;
+    while (chunks * 4 < n_rt && bm_gather_span(n_lt) * chunks * 2 <= 64) chunks <<= 1;
+    return chunks;
+}
 constexpr float kBmBoxCut = 14400.0f * 1.00005f;  // (8 * 15 A)^2 in record units, padded for the rounding of the box test
 
 __device__ __forceinline__ uint32_t bm_cvt_u32(float f) {  // v_cvt_u32_f32 saturates: negative and NaN -> 0
@@ -60,13 +77,6 @@ __device__ __forceinline__ void bm_apply(const Affine &A, float x, float y, floa
     uy = __builtin_fmaf(A.r10, x, __builtin_fmaf(A.r11, y, __builtin_fmaf(A.r12, z, A.ty)));
     uz = __builtin_fmaf(A.r20, x, __builtin_fmaf(A.r21, y, __builtin_fmaf(A.r22, z, A.tz)));
 }
-__device__ __forceinline__ Affine bm_load_affine(const float *rt, size_t pose) {
-    const float4 a = reinterpret_cast<const float4 *>(rt + pose * 12)[0];
-    const float4 b = reinterpret_cast<const float4 *>(rt + pose * 12)[1];
-    const float4 c = reinterpret_cast<const float4 *>(rt + pose * 12)[2];
-    return Affine{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
-}
-
 __device__ __forceinline__ TiledLigand bm_ligand(BmArgs *T) {
     TiledLigand l;
     l.n_real = T->m.lig.n_real;
@@ -148,11 +158,31 @@ __device__ __forceinline__ uint32_t bm_rows_of(unsigned long long mask) {
 template <bool COUNT>
 __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
-    extern __shared__ unsigned long long s_cull[];   // [wave][pose of the wave][receptor tile]: block mask, 0 = not within reach
+    // LDS: the receptor's subtile and tile boxes (read by every item; a global load per surviving tile was most of an
+    // item's time), then [wave][pose of the wave][receptor tile]: block mask, 0 = not within reach
+    extern __shared__ unsigned long long s_cull[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
-    unsigned long long *s_mask = s_cull + (size_t)wave * kBmCullPoses * n_rt;
+    TiledBox *s_sub = reinterpret_cast<TiledBox *>(s_cull);            // [n_rt * 8]
+    TiledBox *s_tile = s_sub + (size_t)n_rt * 8;                        // [n_rt]
+    // per wave: the HITS (pose of the wave, receptor tile, block mask) of the item so far, room for kBmCullHitTiles * n_rt of
+    // them (a pose adds at most n_rt; the list is flushed when the next pose might not fit), and per receptor tile a counter
+    // and the first entry of the wave in that tile pair's list
+    const int hit_cap = bm_cull_hit_cap(n_rt);
+    unsigned char *s_wave = reinterpret_cast<unsigned char *>(s_tile + n_rt) + (size_t)wave * bm_cull_wave_lds(n_rt);
+    unsigned long long *s_hmask = reinterpret_cast<unsigned long long *>(s_wave);          // [hit_cap]
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_hmask + hit_cap);                      // [n_rt]
+    uint32_t *s_base = s_cnt + n_rt;                                                        // [n_rt]
+    unsigned short *s_hkey = reinterpret_cast<unsigned short *>(s_base + n_rt);             // [hit_cap]: pose of the wave << 8 | receptor tile
+    unsigned short *s_hrank = s_hkey + hit_cap;                                             // [hit_cap]: place among the wave's hits of that tile pair
+    {
+        static_assert(sizeof(TiledBox) == 32, "two 16-byte pieces");
+        const uint4 *src_sub = reinterpret_cast<const uint4 *>(T->m.rec_sub), *src_tile = reinterpret_cast<const uint4 *>(T->m.rec_tile);
+        for (int k = threadIdx.x; k < n_rt * 16; k += kBmCullWaves * 64) reinterpret_cast<uint4 *>(s_sub)[k] = src_sub[k];
+        for (int k = threadIdx.x; k < n_rt * 2; k += kBmCullWaves * 64) reinterpret_cast<uint4 *>(s_tile)[k] = src_tile[k];
+        __syncthreads();
+    }
     const size_t rows = bm_rows(T);
     const size_t n_items = (rows + kBmCullPoses - 1) / kBmCullPoses * (size_t)n_lt;
     const float ubound = T->m.ubound, pad = T->m.box_pad;
@@ -167,29 +197,98 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     const float4 loc = reinterpret_cast<const float4 *>(T->m.lig_local)[la];
     const bool valid = loc.w != 0.f;
     const float4 sphere = reinterpret_cast<const float4 *>(T->m.lig_tile_sphere)[lt];
-    // this lane's receptor tile box (the first 64 tiles; larger receptors load the rest per pose)
+    // this lane's receptor tile box (the first 64 tiles; larger receptors read the rest per pose)
     TiledBox my_tile = TiledBox{INFINITY, INFINITY, INFINITY, 0.f, -INFINITY, -INFINITY, -INFINITY, 0.f};
-    if (lane < n_rt) my_tile = T->m.rec_tile[lane];
-    for (int k = lane; k < kBmCullPoses * n_rt; k += 64) s_mask[k] = 0ull;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < n_rt) my_tile = s_tile[lane];
+
+    // the item's poses and their affine maps: lane g loads those of pose g, all in flight together
+    long long my_pose = -1;
+    float4 my_a0 = float4{0.f, 0.f, 0.f, 0.f}, my_a1 = my_a0, my_a2 = my_a0;
+    if (lane < kBmCullPoses && listed0 + lane < rows) my_pose = bm_pose_of(T, listed0 + lane);
+    if (my_pose >= 0) {
+        const float4 *ap = reinterpret_cast<const float4 *>(T->rt + (size_t)my_pose * 12);
+        my_a0 = ap[0];
+        my_a1 = ap[1];
+        my_a2 = ap[2];
+    }
+    auto pose_lane = [](float v, int g) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), g)); };
+    auto affine_of = [&](int g) {
+        return Affine{pose_lane(my_a0.x, g), pose_lane(my_a0.y, g), pose_lane(my_a0.z, g), pose_lane(my_a0.w, g),
+                      pose_lane(my_a1.x, g), pose_lane(my_a1.y, g), pose_lane(my_a1.z, g), pose_lane(my_a1.w, g),
+                      pose_lane(my_a2.x, g), pose_lane(my_a2.y, g), pose_lane(my_a2.z, g), pose_lane(my_a2.w, g)};
+    };
+
+    uint32_t n_hits = 0;                 // wave-uniform: hits listed and not flushed yet
+    uint32_t my_first = 0, my_nvis = 0;  // lane g: where pose g's hits start in the list; how many it has
+    // ---- the list -> entries.  One LDS atomic per hit (its place among the wave's hits of the tile pair), ONE global atomic per
+    // tile pair for the whole wave (the lists of a small complex have few heads: one returning atomic per pose and tile pair
+    // serialises on them), then lane = hit writes the entry.
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int k = lane; k < n_rt; k += 64) s_cnt[k] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t h = (uint32_t)lane; h < n_hits; h += 64) s_hrank[h] = (unsigned short)atomicAdd(&s_cnt[s_hkey[h] & 0xffu], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int k = lane; k < n_rt; k += 64) {
+            const uint32_t total = s_cnt[k];
+            if (total) s_base[k] = atomicAdd(&T->tp_count[(size_t)lt * n_rt + k], total);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t h0 = 0; h0 < n_hits; h0 += 64) {
+            const uint32_t h = h0 + (uint32_t)lane;
+            const bool act = h < n_hits;
+            const uint32_t key = act ? s_hkey[h] : 0u;
+            const int g = (int)(key >> 8), RT = (int)(key & 0xffu);
+            // what lane g holds about pose g (every lane takes part in the shuffles)
+            const uint32_t pose = (uint32_t)__shfl((int)(uint32_t)my_pose, g, 64);
+            const uint32_t first = (uint32_t)__shfl((int)my_first, g, 64);
+            const float4 a0 = float4{__shfl(my_a0.x, g, 64), __shfl(my_a0.y, g, 64), __shfl(my_a0.z, g, 64), __shfl(my_a0.w, g, 64)};
+            const float4 a1 = float4{__shfl(my_a1.x, g, 64), __shfl(my_a1.y, g, 64), __shfl(my_a1.z, g, 64), __shfl(my_a1.w, g, 64)};
+            const float4 a2 = float4{__shfl(my_a2.x, g, 64), __shfl(my_a2.y, g, 64), __shfl(my_a2.z, g, 64), __shfl(my_a2.w, g, 64)};
+            if (act) {
+                const unsigned long long mask = s_hmask[h];
+                const uint32_t idx = s_base[RT] + s_hrank[h];
+                const size_t at = ((size_t)lt * n_rt + RT) * T->cap + idx;
+                T->ent_pose[at] = pose;
+                T->ent_mask[at] = mask;
+                float4 *ap = reinterpret_cast<float4 *>(T->ent_rt) + at * 3;   // (what a pair batch poses the entry with)
+                ap[0] = a0;
+                ap[1] = a1;
+                ap[2] = a2;
+                T->vis_entry[((size_t)pose * n_lt + lt) * (size_t)n_rt + (h - first)] =
+                    (unsigned long long)RT << 48 | (unsigned long long)bm_rows_of(mask) << 32 | idx;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the list is read before it is written again
+        n_hits = 0;
+    };
 
     long long pose_of[kBmCullPoses];   // wave-uniform
 #pragma unroll
     for (int g = 0; g < kBmCullPoses; g++) {
-        const size_t listed = listed0 + g;
-        pose_of[g] = listed < rows ? bm_pose_of(T, listed) : -1;
+        pose_of[g] = (long long)((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_pose, g) |
+                                 (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)my_pose >> 32), g) << 32);
         if (pose_of[g] < 0) continue;
         const size_t pose = (size_t)pose_of[g];
-        const Affine A = bm_load_affine(T->rt, pose);
-        {   // a tile whose bounding sphere stays beyond the cutoff of the receptor's box has nothing to list (most tiles
-            // of a large ligand, in most poses): one point posed instead of 64 atoms, boxes and tile tests
+        const Affine A = affine_of(g);
+        if (n_hits + (uint32_t)n_rt > (uint32_t)hit_cap) flush();
+        const uint32_t first_hit = n_hits;
+        if (lane == g) my_first = first_hit;
+        {   // A tile whose bounding sphere stays beyond the cutoff of every receptor tile's box has nothing to list (most tiles
+            // of a large ligand, in most poses): one point posed and one test per receptor tile instead of 64 atoms posed,
+            // their boxes and the box tests.
             float sx, sy, sz;
             bm_apply(A, sphere.x, sphere.y, sphere.z, sx, sy, sz);
-            const float gx = fmaxf(0.f, fmaxf(T->m.rec_lo[0] - sx, sx - T->m.rec_hi[0]));
-            const float gy = fmaxf(0.f, fmaxf(T->m.rec_lo[1] - sy, sy - T->m.rec_hi[1]));
-            const float gz = fmaxf(0.f, fmaxf(T->m.rec_lo[2] - sz, sz - T->m.rec_hi[2]));
             const float reach = 120.0f * 1.0001f + sphere.w + pad;   // (8 * 15 A, the sphere's radius, the affine map's error)
-            if (gx * gx + gy * gy + gz * gz > reach * reach) {
+            bool any_near = false;
+            for (int base = 0; base < n_rt && !any_near; base += 64) {
+                const TiledBox tb = base == 0 ? my_tile : (base + lane < n_rt ? s_tile[base + lane] : my_tile);
+                const float gx = fmaxf(0.f, fmaxf(tb.lox - sx, sx - tb.hix));
+                const float gy = fmaxf(0.f, fmaxf(tb.loy - sy, sy - tb.hiy));
+                const float gz = fmaxf(0.f, fmaxf(tb.loz - sz, sz - tb.hiz));
+                any_near = __ballot(base + lane < n_rt && gx * gx + gy * gy + gz * gz <= reach * reach) != 0ull;
+            }
+            if (!any_near) {
                 if (COUNT && lane == 0) T->tile_tested[pose * (size_t)n_lt + lt] = 0;
                 continue;
             }
@@ -221,7 +320,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         for (int base = 0; base < n_rt; base += 64) {
             bool tile_near = false;
             if (base == 0) tile_near = lane < n_rt && box_gap2(whole, my_tile) <= kBmBoxCut;
-            else if (base + lane < n_rt) tile_near = box_gap2(whole, T->m.rec_tile[base + lane]) <= kBmBoxCut;
+            else if (base + lane < n_rt) tile_near = box_gap2(whole, s_tile[base + lane]) <= kBmBoxCut;
             unsigned long long rtmask = __ballot(tile_near);
             while (rtmask) {
                 // four surviving tiles at a time: their subtile boxes are loaded together
@@ -234,63 +333,27 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                 }
                 TiledBox nb[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) nb[k] = T->m.rec_sub[(size_t)RTs[k] * 8 + bj];
+                for (int k = 0; k < 4; k++) nb[k] = s_sub[RTs[k] * 8 + bj];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if (k >= nk) break;
                     const unsigned long long smask = __ballot(box_gap2(sub, nb[k]) <= kBmBoxCut);  // bit = ligand subtile (lane >> 3) * 8 + receptor subtile
-                    if (smask && lane == 0) s_mask[g * n_rt + RTs[k]] = smask;
+                    if (smask) {
+                        if (lane == 0) {
+                            s_hmask[n_hits] = smask;
+                            s_hkey[n_hits] = (unsigned short)(g << 8 | RTs[k]);
+                        }
+                        n_hits++;
+                    }
                     if (COUNT) tested += (uint32_t)__popcll(smask);
                 }
             }
         }
         if (COUNT && lane == 0) T->tile_tested[pose * (size_t)n_lt + lt] = tested;
+        if (lane == g) my_nvis = n_hits - first_hit;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
-    // ---- phase 2: lane = receptor tile
-    uint32_t n_vis[kBmCullPoses];   // per pose: surviving tiles listed so far (wave-uniform)
-#pragma unroll
-    for (int g = 0; g < kBmCullPoses; g++) n_vis[g] = 0;
-    for (int base = 0; base < n_rt; base += 64) {
-        const int RT = base + lane;
-        const size_t tp = (size_t)lt * n_rt + (RT < n_rt ? RT : 0);
-        unsigned long long mk[kBmCullPoses];
-        uint32_t k = 0;
-#pragma unroll
-        for (int g = 0; g < kBmCullPoses; g++) {
-            mk[g] = RT < n_rt && pose_of[g] >= 0 ? s_mask[g * n_rt + RT] : 0ull;
-            k += mk[g] ? 1u : 0u;
-        }
-        uint32_t idx = k ? atomicAdd(&T->tp_count[tp], k) : 0u;
-#pragma unroll
-        for (int g = 0; g < kBmCullPoses; g++) {
-            const unsigned long long live = __ballot(mk[g] != 0ull);
-            if (pose_of[g] < 0 || live == 0ull) continue;
-            const size_t pose = (size_t)pose_of[g];
-            const size_t slot = pose * (size_t)n_lt + lt;
-            if (mk[g]) {
-                const Affine A = bm_load_affine(T->rt, pose);   // (uniform; what a pair batch poses the entry with)
-                const size_t at = tp * T->cap + idx;
-                T->ent_pose[at] = (uint32_t)pose;
-                T->ent_mask[at] = mk[g];
-                float4 *ap = reinterpret_cast<float4 *>(T->ent_rt) + at * 3;
-                ap[0] = float4{A.r00, A.r01, A.r02, A.tx};
-                ap[1] = float4{A.r10, A.r11, A.r12, A.ty};
-                ap[2] = float4{A.r20, A.r21, A.r22, A.tz};
-                const uint32_t v = n_vis[g] + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-                T->vis_entry[slot * (size_t)n_rt + v] = (unsigned long long)RT << 48 | (unsigned long long)bm_rows_of(mk[g]) << 32 | idx;
-                idx++;
-            }
-            n_vis[g] += (uint32_t)__popcll(live);
-        }
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int g = 0; g < kBmCullPoses; g++)
-            if (pose_of[g] >= 0) T->vis_count[(size_t)pose_of[g] * n_lt + lt] = n_vis[g];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the masks in LDS are read before the next item clears them
+    flush();
+    if (my_pose >= 0) T->vis_count[(size_t)my_pose * n_lt + lt] = my_nvis;
     }
 }
 
@@ -317,7 +380,10 @@ __global__ __launch_bounds__(1024) void dfire_bm_plan(const BmLaunch launch_argu
     __syncthreads();
     // about one (tile pair, part) pair per wave of the pair kernel, i.e. kBmJobRows jobs per wave
     const uint32_t waves = (uint32_t)(T->pairs_groups > 0 ? T->pairs_groups : 256) * kBmWaves;
-    uint32_t P = (s_total / waves + 63u) / 64u * 64u;
+#ifndef LD_BM_P_FACTOR
+#define LD_BM_P_FACTOR 4
+#endif
+    uint32_t P = (s_total * LD_BM_P_FACTOR / waves + 63u) / 64u * 64u;
     P = P < 64u ? 64u : P > (uint32_t)kBmPartEntries ? (uint32_t)kBmPartEntries : P;
     const uint32_t step = P / 16u;
     for (uint32_t tp = tid; tp < n_tp; tp += 1024) {
@@ -359,20 +425,18 @@ __global__ __launch_bounds__(1024) void dfire_bm_plan(const BmLaunch launch_argu
 }
 
 // ---------------------------------------------------------------------------------------------
-// dfire_bm_order: how long is each job, and in which order should the waves of dfire_bm_pairs draw them?  A job's length
+// dfire_bm_census + dfire_bm_order: how long is each job, and in which order should the waves of dfire_bm_pairs draw them?  A job's length
 // is set by the block bits of its entries (16 on average of the 64 a mask has room for, between 0 and 8 in a row), not
 // by the number of entries: jobs of equal entry count differ eightfold.  Every wave takes (tile pair, part) pairs, counts
 // per row the block bits of the part's entries and the distinct blocks, and writes an estimate in units of 1/64 batch:
 //   items + 96 per block present (staging, the last batch's empty lanes) + 224 (job set-up)
-// The workgroup that finishes last then lists the jobs that have any work by class of estimated length, longest first
+// dfire_bm_order (one workgroup) then lists the jobs that have any work by class of estimated length, longest first
 // (counting sort in LDS): the launch ends on jobs of a few batches, and rows without a block are never drawn.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBmOrderWaves = 16;
-__global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_order(const BmLaunch launch_arguments) {
+__global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_census(const BmLaunch launch_arguments) {
     static_assert(kBmJobRows == 8 && kBmHalves == 1 && kBmSplit == 1, "a job row is one byte of the block mask");
     BmArgs *T = LD_BM_ARGS;
-    __shared__ uint32_t s_class[kBmCostClasses];
-    __shared__ uint32_t s_last;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t n_pairs = T->job_count[0], P = T->job_count[2];
@@ -413,19 +477,29 @@ __global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_order(const BmLau
             T->job_cost[(size_t)jd * kBmJobRows + lane] = it ? it + 96u * blocks + 224u : 0u;
         }
     }
-    // the last workgroup to get here orders the jobs
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(T->job_count + 4, 1u) == gridDim.x - 1 ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_order(const BmLaunch launch_arguments) {
+    BmArgs *T = LD_BM_ARGS;
+    __shared__ uint32_t s_class[kBmCostClasses];
+    const int tid = threadIdx.x;
+    const uint32_t n_pairs = T->job_count[0];
     for (int c = tid; c < kBmCostClasses; c += kBmOrderWaves * 64) s_class[c] = 0;
     __syncthreads();
-    if (!s_last) return;
-    __threadfence();
     const uint32_t n_jobs = n_pairs * (uint32_t)kBmJobRows;
     auto class_of = [](uint32_t cost) { const uint32_t c = cost >> 7; return c < (uint32_t)kBmCostClasses ? c : (uint32_t)kBmCostClasses - 1u; };
-    for (uint32_t j = tid; j < n_jobs; j += kBmOrderWaves * 64) {
-        const uint32_t cost = __builtin_nontemporal_load(T->job_cost + j);
-        if (cost) atomicAdd(&s_class[class_of(cost)], 1u);
+    // (eight loads in flight per thread: one at a time, the two passes over ~20 000 jobs took 60 us)
+    constexpr uint32_t kStep = kBmOrderWaves * 64;
+    for (uint32_t base = 0; base < n_jobs; base += 8 * kStep) {
+        uint32_t cost[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t j = base + (uint32_t)u * kStep + (uint32_t)tid;
+            cost[u] = j < n_jobs ? T->job_cost[j] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (cost[u]) atomicAdd(&s_class[class_of(cost[u])], 1u);
     }
     __syncthreads();
     if (tid == 0) {
@@ -438,9 +512,16 @@ __global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_order(const BmLau
         T->job_count[3] = at;
     }
     __syncthreads();
-    for (uint32_t j = tid; j < n_jobs; j += kBmOrderWaves * 64) {
-        const uint32_t cost = __builtin_nontemporal_load(T->job_cost + j);
-        if (cost) T->job_order[atomicAdd(&s_class[class_of(cost)], 1u)] = j;
+    for (uint32_t base = 0; base < n_jobs; base += 8 * kStep) {
+        uint32_t cost[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t j = base + (uint32_t)u * kStep + (uint32_t)tid;
+            cost[u] = j < n_jobs ? T->job_cost[j] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (cost[u]) T->job_order[atomicAdd(&s_class[class_of(cost[u])], 1u)] = base + (uint32_t)u * kStep + (uint32_t)tid;
     }
 }
 
@@ -817,9 +898,11 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
     // thread = (pose, ligand tile); a workgroup holds 512 / span poses, span = the power of two that covers the ligand's
     // tiles.  The kernel is bound by the latency of three dependent loads per entry: many poses in flight per CU, and
     // per thread the partial sums of four entries x all their rows requested together.
-    int span = 1;
-    while (span < n_lt && span < 512) span <<= 1;
+    // A small ligand leaves threads over: `chunks` of them share a (pose, ligand tile), each taking every chunks-th group of
+    // four entries (both numbers depend on the molecules only: a pose's sum is the same tree in every launch).
+    const int span_lt = bm_gather_span(n_lt), chunks = bm_gather_chunks(n_lt, n_rt), span = span_lt * chunks;
     const int per_wg = 512 / span, sub = tid / span, r0 = tid % span;
+    const int lt0 = r0 / chunks, chunk = r0 % chunks;
     const size_t n_rows = bm_rows(T);
     for (size_t first_row = (size_t)blockIdx.x * per_wg; first_row < n_rows; first_row += (size_t)gridDim.x * per_wg) {
     const size_t listed = first_row + sub;
@@ -827,11 +910,11 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
     const size_t pose = pp < 0 ? 0 : (size_t)pp;
     double s = 0.0;
     uint32_t cnt = 0, tested = 0;
-    for (int lt = r0; pp >= 0 && lt < n_lt; lt += span) {   // the tile's entries in the order the culling listed them, their rows in order
+    for (int lt = lt0; pp >= 0 && lt < n_lt; lt += span_lt) {   // the tile's entries in the order the culling listed them, their rows in order
         const size_t slot = pose * (size_t)n_lt + lt;
-        if (COUNT) tested += T->tile_tested[slot];
+        if (COUNT && chunk == 0) tested += T->tile_tested[slot];
         const uint32_t n_vis = T->vis_count[slot];
-        for (uint32_t v0 = 0; v0 < n_vis; v0 += 4) {
+        for (uint32_t v0 = 4u * (uint32_t)chunk; v0 < n_vis; v0 += 4u * (uint32_t)chunks) {
             unsigned long long ent[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) ent[k] = v0 + k < n_vis ? T->vis_entry[slot * (size_t)n_rt + v0 + k] : 0ull;
@@ -900,9 +983,18 @@ hipError_t launch_bm_pose(const BmLaunch &t, hipStream_t stream) {
 
 hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    const size_t blocks = std::min<size_t>(((t.n_poses + kBmCullPoses - 1) / kBmCullPoses * (size_t)t.m.lig.n_tiles + kBmCullWaves - 1) / kBmCullWaves, 32768);
     if (t.m.rec_n_tiles > 255) return hipErrorInvalidValue;
-    const size_t lds = (size_t)kBmCullWaves * kBmCullPoses * t.m.rec_n_tiles * sizeof(unsigned long long);
+    const size_t lds = (size_t)t.m.rec_n_tiles * 9 * sizeof(TiledBox) + (size_t)kBmCullWaves * bm_cull_wave_lds(t.m.rec_n_tiles);
+    // persistent workgroups (each fills its LDS with the receptor's boxes once): as many as fit the chip at this LDS size
+    const size_t per_cu = std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512)));
+    const size_t cus = t.pairs_groups > 0 ? (size_t)t.pairs_groups : 256;
+    const size_t blocks = std::min<size_t>(((t.n_poses + kBmCullPoses - 1) / kBmCullPoses * (size_t)t.m.lig.n_tiles + kBmCullWaves - 1) / kBmCullWaves, cus * per_cu);
+    if (lds > 64 * 1024) {   // (a receptor of more than ~100 tiles)
+        const hipError_t e = t.ent_count != nullptr
+            ? hipFuncSetAttribute(reinterpret_cast<const void *>(&dfire_bm_cull<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+            : hipFuncSetAttribute(reinterpret_cast<const void *>(&dfire_bm_cull<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_cull<true>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
     else hipLaunchKernelGGL((dfire_bm_cull<false>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
     return hipGetLastError();
@@ -911,7 +1003,8 @@ hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream) {
 hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
     hipLaunchKernelGGL(dfire_bm_plan, dim3(1), dim3(1024), 0, stream, t);
-    hipLaunchKernelGGL(dfire_bm_order, dim3(128), dim3(kBmOrderWaves * 64), 0, stream, t);
+    hipLaunchKernelGGL(dfire_bm_census, dim3(128), dim3(kBmOrderWaves * 64), 0, stream, t);
+    hipLaunchKernelGGL(dfire_bm_order, dim3(1), dim3(kBmOrderWaves * 64), 0, stream, t);
     const unsigned groups = t.pairs_groups > 0 ? (unsigned)t.pairs_groups : 256u;   // persistent: one workgroup per CU
     if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_pairs<true>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
     else hipLaunchKernelGGL((dfire_bm_pairs<false>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
@@ -920,8 +1013,7 @@ hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
 
 hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    int span = 1;
-    while (span < t.m.lig.n_tiles && span < 512) span <<= 1;
+    const int span = bm_gather_span(t.m.lig.n_tiles) * bm_gather_chunks(t.m.lig.n_tiles, t.m.rec_n_tiles);
     const size_t per_wg = 512 / span;
     const unsigned blocks = (unsigned)std::min<size_t>((t.n_poses + per_wg - 1) / per_wg, 16384);
     if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_gather<true>), dim3(blocks), dim3(512), 0, stream, t);

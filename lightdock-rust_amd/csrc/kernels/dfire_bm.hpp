@@ -86,7 +86,6 @@ struct BmModel {
     const float *lig_local = nullptr;           // [n_tiles*64][4]: x, y, z (angstrom, f32), 1.0 = real atom
     const uint32_t *lig_rowbase = nullptr;      // [n_tiles*64]: byte offset of the atom's type block in `rows`
     const float *lig_tile_sphere = nullptr;     // [n_tiles][4]: centre (local, angstrom) and radius (record units, rounded up) of a sphere around the tile
-    float rec_lo[3] = {0, 0, 0}, rec_hi[3] = {0, 0, 0};   // the receptor's box in record units
     // tables
     const double *rows = nullptr;               // [kBmTypes lig][kBmTypes rec][kBmRowSlots]
     const uint8_t *lut = nullptr;               // kBmLutBytes codes, cell' = floor(kBmCellMax + 1/2 - 64 d2)

@@ -827,16 +827,6 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
             sphere[4 * t + 3] = std::nextafter((float)(kBmKappa * r * 1.000001 + 1e-3), INFINITY);
         }
         M.lig_tile_sphere = arena_.upload(sphere);
-        double rlo[3] = {1e300, 1e300, 1e300}, rhi[3] = {-1e300, -1e300, -1e300};
-        for (size_t i = 0; i < desc.receptor.n_atoms; i++)
-            for (int k = 0; k < 3; k++) {
-                rlo[k] = std::min(rlo[k], desc.receptor.coordinates[3 * i + k]);
-                rhi[k] = std::max(rhi[k], desc.receptor.coordinates[3 * i + k]);
-            }
-        for (int k = 0; k < 3; k++) {   // record units, rounded outwards
-            M.rec_lo[k] = std::nextafter((float)(kBmKappa * (rlo[k] - centre[k]) - 1e-3), -INFINITY);
-            M.rec_hi[k] = std::nextafter((float)(kBmKappa * (rhi[k] - centre[k]) + 1e-3), INFINITY);
-        }
     }
     {   // rows[l][r][0] = 0.0; rows[l][r][bm_slot_of_bin(b)] = potential[r * 3380 + l * 20 + b], b = 0..20 (20 = the read past the row, src/dfire.rs:338)
         std::vector<double> rows((size_t)kBmTypes * kBmTypes * kBmRowSlots, 0.0);
