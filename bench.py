@@ -407,8 +407,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": prof.get("hbm_bytes_per_launch"),
                          "kernel": info["pair_kernel_name"], "kernel_ms": 1e3 * kern_s,
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
-                         "note": "algorithmic bytes (SURVEY 8d) over kernel time; the working set is L2 resident, so measured HBM "
-                                 "traffic (`traffic`) is far below it and the binding limits are on chip -- see `l2`, `l1`, `compute`",
+                         "note": ("algorithmic bytes (SURVEY 8d) over kernel time; `kernel_ms` brackets the whole block-major sequence "
+                                  "(memset, dfire_bm_pose, _cull, _plan, _census, _order, _pairs, _gather) and `traffic`, `compute`, `binding` "
+                                  "are sums over it; the pair kernel stages table rows in LDS, so its HBM traffic is the entries' affine "
+                                  "maps and partial sums, not the table") if info["pair_kernel_name"].startswith("dfire_bm") else
+                                 ("algorithmic bytes (SURVEY 8d) over kernel time; the working set is L2 resident, so measured HBM "
+                                  "traffic (`traffic`) is far below it and the binding limits are on chip -- see `l2`, `l1`, `compute`"),
                          "profile_stale": stale, "binding": binding, "compute": compute, "l1": l1, "l2": l2,
                          "nominal_pair_tests_per_s": info["pair_tests_per_pose"] * units_per_launch / kern_s,
                          "evaluated_pair_tests_per_s": (64.0 * blocks * units_per_launch / kern_s) if blocks else None},

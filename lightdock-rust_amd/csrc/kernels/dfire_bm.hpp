@@ -52,10 +52,7 @@ constexpr int kBmLig = 8;                    // ligand atoms per job row: a job 
 constexpr int kBmSplit = 8 / kBmLig;         // job rows per ligand subtile
 constexpr int kBmRows = 8 * kBmSplit;        // job rows per ligand tile
 constexpr int kBmCubeRows = kBmLig * 8;
-#ifndef LD_BM_HALVES
-#define LD_BM_HALVES 1
-#endif
-constexpr int kBmHalves = LD_BM_HALVES;                 // a job walks 8 / kBmHalves of its row's blocks: shorter jobs, a shorter tail of the launch
+constexpr int kBmHalves = 1;                 // a job walks 8 / kBmHalves of its row's blocks (2 was measured: shorter jobs, twice the set-ups; slower)
 constexpr int kBmJobRows = kBmRows * kBmHalves;   // partial sums per entry
 constexpr int kBmCubeBytes = kBmCubeRows * kBmRowBytes + 16;  // + one zero slot behind the last row
 constexpr uint32_t kBmFlagged = kBmRowBytes;  // LUT code of a flagged cell: slot 0 of the NEXT row = 0.0, above every bin code

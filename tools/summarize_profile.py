@@ -8,7 +8,7 @@ import os
 import sys
 
 out = sys.argv[1]
-KERNELS = ("dfire_bm_pairs<false", "dfire_bm_cull<false", "dfire_bm_gather<false", "dfire_bm_pose", "dfire_bm_plan",
+KERNELS = ("dfire_bm_pairs<false", "dfire_bm_cull<false", "dfire_bm_gather<false", "dfire_bm_pose", "dfire_bm_plan", "dfire_bm_census", "dfire_bm_order",
            "dfire_packed_pairs<false", "dfire_tiled_pairs<false", "pose_energy_pairs<1", "pose_energy_pairs<0", "gso_movement_phase",
            "pose_energy_finish", "dfire_packed_prepare")
 
@@ -33,14 +33,14 @@ def counters():
 print("== kernel trace (rocprofv3 --kernel-trace --stats) of: bench.py --workload %s --steps 10 --warmup 3" % os.path.basename(out.rstrip("/")))
 for p in glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv")):
     for i, r in enumerate(csv.DictReader(open(p))):
-        if i < 9:
+        if i < 11:
             print("  %-84s calls %5s avg %12.1f ns  %6s %%" % (r["Name"][:84], r["Calls"], float(r["AverageNs"]), r["Percentage"]))
-    # the block-major K1 is five kernels; bench.py's HIP events bracket all of them (`roofline.kernel_ms`)
+    # the block-major K1 is seven kernels; bench.py's HIP events bracket all of them (`roofline.kernel_ms`)
     rows = list(csv.DictReader(open(p)))
     bm = [r for r in rows if "dfire_bm_" in r["Name"] and "<true>" not in r["Name"]]
     if bm:
         calls = max(int(r["Calls"]) for r in bm if "pairs" in r["Name"])
-        print("  block-major K1 (pose + cull + plan + pairs + gather), sum of the average durations: %.1f ns over %d launches of the sequence"
+        print("  block-major K1 (pose + cull + plan + census + order + pairs + gather), sum of the average durations: %.1f ns over %d launches of the sequence"
               % (sum(float(r["TotalDurationNs"]) for r in bm) / calls, calls))
 try:
     b = json.load(open(os.path.join(out, "bench_traced.json")))

@@ -35,11 +35,18 @@ for wdir in sorted(glob.glob(os.path.join(src, "*"))):
     units = b["config"].get("poses_per_step_per_gpu") or b["config"].get("swarms_this_rank")
     text = open(os.path.join(wdir, "summary.txt")).read()
     # the section of the dominant kernel
-    m = re.search(r"== PMC, mean per launch of %s[^\n]*\n(.*?)(?:\n==|\Z)" % re.escape(kernel + "<false" if kernel.startswith("dfire") else kernel), text, re.S)
-    sec = m.group(1) if m else ""
+    # The block-major K1 is a sequence of kernels that bench.py times as one (`roofline.kernel_ms`): its counters are the sums
+    # over the sequence.  Every other kernel: its own section.
+    secs = re.findall(r"== PMC, mean per launch of ([^\n]*)\n(.*?)(?=\n==|\Z)", text, re.S)
+    if kernel.startswith("dfire_bm"):
+        mine = [body for name, body in secs if name.startswith("dfire_bm_")]
+    else:
+        want = kernel + "<false" if kernel.startswith("dfire") else kernel
+        mine = [body for name, body in secs if name.startswith(want)][:1]
     def val(key):
-        mm = re.search(r"^\s*%s\s+([0-9.e+]+)" % re.escape(key), sec, re.M)
-        return float(mm.group(1)) if mm else None
+        found = [re.search(r"^\s*%s\s+([0-9.e+]+)" % re.escape(key), body, re.M) for body in mine]
+        found = [float(mm.group(1)) for mm in found if mm]
+        return sum(found) if found else None
     entry = {"source_hash": h, "source": "profiles/%s_%s_summary.txt" % (tag, name)}
     for key, field in (("traffic_json hbm_bytes_per_launch", "hbm_bytes_per_launch"), ("SQ_INSTS_VALU", "valu_insts_per_launch"),
                        ("SQ_INSTS_SALU", "salu_insts_per_launch"), ("SQ_INSTS_VMEM_RD", "vmem_insts_per_launch"),
@@ -48,8 +55,12 @@ for wdir in sorted(glob.glob(os.path.join(src, "*"))):
         v = val(key)
         if v is not None:
             entry[field] = v
-    entry["valu_source"] = "SQ_INSTS_VALU (wave-level vector instructions) per launch of %s, same file" % kernel
+    entry["valu_source"] = "SQ_INSTS_VALU (wave-level vector instructions) per launch of %s, same file" % (
+        "the block-major sequence (pose, cull, plan, census, order, pairs, gather)" if kernel.startswith("dfire_bm") else kernel)
     entry["binding"] = "valu-issue"
+    if kernel.startswith("dfire_bm"):
+        entry["kernels"] = {name.split("<")[0]: float(re.search(r"^\s*SQ_INSTS_VALU\s+([0-9.e+]+)", body, re.M).group(1))
+                            for name, body in secs if name.startswith("dfire_bm_") and re.search(r"^\s*SQ_INSTS_VALU", body, re.M)}
     traffic["%s:%d:%s" % (w, units, kernel)] = entry
     print("%s:%d:%s" % (w, units, kernel), {k: v for k, v in entry.items() if k not in ("source", "valu_source")})
 json.dump(traffic, open(tj, "w"), indent=1)
