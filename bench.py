@@ -148,12 +148,17 @@ KERNEL_SOURCES = ("lightdock-rust_amd/csrc/kernels/dfire_bm.hip", "lightdock-rus
 
 def kernel_source_hash():
     """What ties a committed counter profile to the build it was taken from: a hash of the kernel sources and of
-    scorer.cpp (launch shapes, LUTs, layouts).  tools/update_traffic.py stamps it on every entry of profiles/traffic.json."""
+    scorer.cpp (launch shapes, LUTs, layouts), comments and whitespace left out.  tools/update_traffic.py stamps it on every entry of profiles/traffic.json."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES:
+        text = open(os.path.join(ROOT, rel), "r", encoding="utf-8", errors="replace").read()
+        # the CODE: comments and layout do not change what a profile measured
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
         h.update(rel.encode())
-        h.update(open(os.path.join(ROOT, rel), "rb").read())
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -4,19 +4,25 @@
 // numerics as dfire_packed.hpp, but the pair work is ordered by atom-pair BLOCK instead of by pose:
 //
 //   dfire_bm_pose    one thread per pose: the pose's rotation + translation as an f32 affine map into the record frame
-//   dfire_bm_cull    one wave per (pose, ligand tile): ligand atoms posed in f32, boxes, 64x64 and 8x8 box tests; every
-//                    surviving (ligand tile, receptor tile) pair of the pose becomes one ENTRY {pose, 64-bit block
-//                    mask} appended to that tile pair's list
-//   dfire_bm_pairs   one workgroup per (tile pair, ligand subtile a): for each of its 8 blocks (a, b) the 64 table
-//                    rows T[type_i][type_j][.] of the block are staged in LDS ONCE (dense L2 -> LDS copies), the
-//                    entries whose mask holds the block are compacted into batches of 64, and a batch runs lane = pose:
-//                    the lane poses the 8 ligand atoms of subtile a (uniform local coordinates, its pose's affine map)
-//                    and walks the 64 atom pairs of the block, whose receptor atoms and table rows are wave-uniform:
-//                    D'' = 64 d2 + 1/2 in packed f32, cell = (u32)D'', code = lut[cell] (u8, LDS), value = row[code]
-//                    (f64, LDS), f64 add.  No gather ever leaves the CU: the L2 -> L1 line fills that bound the
-//                    pose-major kernel (0.5 lines of 128 B per in-cutoff pair) are gone.
-//   dfire_bm_gather  one wave per pose: the pose's partial sums in a fixed order -> the [pose][1][2] partials that
-//                    pose_energy_finish folds (restraint / membrane tail, src/dfire.rs:347-361)
+//   dfire_bm_cull    persistent waves, one (ligand tile, 8 poses) item at a time: a bounding-sphere test of the tile against the
+//                    receptor's tile boxes (in LDS), then the ligand atoms posed in f32, boxes, 64x64 and 8x8 box tests; every
+//                    surviving (ligand tile, receptor tile) pair of a pose becomes one ENTRY {pose, 64-bit block mask, the
+//                    pose's affine map} appended to that tile pair's list (one global atomic per tile pair per wave)
+//   dfire_bm_plan    one workgroup: every tile pair's entries cut into parts of P entries
+//   dfire_bm_census  one wave per (tile pair, part): per ligand-subtile row the block bits of its entries -> the estimated
+//                    length of the JOB (tile pair, part, row)
+//   dfire_bm_order   one workgroup: the jobs that have any work, longest first (counting sort into classes)
+//   dfire_bm_pairs   persistent workgroups of 8 independent waves (one per CU); a wave draws a job and, for each of its 8
+//                    blocks (a, b): the 64 table rows T[type_i][type_j][.] of the block are staged in the wave's slice of LDS
+//                    ONCE (dense L2 -> LDS copies by LDS-DMA), the entries whose mask holds the block are compacted into
+//                    batches of 64, and a batch runs lane = pose: the lane poses the 8 ligand atoms of subtile a (uniform
+//                    local coordinates, its pose's affine map) and walks the 64 atom pairs of the block, whose receptor
+//                    atoms and table rows are wave-uniform: E = cell-zero + 1/2 - 64 d2 in packed f32 (coordinates relative
+//                    to the receptor subtile's box centre), cell = (u32)E, code = lut[cell] (u8, LDS), value = row[code]
+//                    (f64, LDS), f64 add.  No gather ever leaves the CU: the L2 -> L1 line fills that bound the pose-major
+//                    kernel (0.5 lines of 128 B per in-cutoff pair) are gone.
+//   dfire_bm_gather  thread = (pose, ligand tile[, share of its entries]): the pose's partial sums in a fixed order -> the
+//                    [pose][1][2] partials that pose_energy_finish folds (restraint / membrane tail, src/dfire.rs:347-361)
 //
 // Numerics: records are u = fl32(8 (x - c)); the ligand is posed by an f32 affine map whose error
 // is part of `eps`; a LUT cell (1/16 of a unit of 4 d2) whose interval, widened by eps, holds a bin step, the interface
