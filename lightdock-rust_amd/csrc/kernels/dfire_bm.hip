@@ -30,6 +30,7 @@ constexpr int kBmCullWaves = LD_BM_CULL_WAVES;   // independent waves per dfire_
 #define LD_BM_CULL_POSES 8
 #endif
 constexpr int kBmCullPoses = LD_BM_CULL_POSES;   // poses a wave of dfire_bm_cull walks with its ligand tile
+constexpr int kBmCullQueues = kBmCullQueueWords;   // (1k4c: 8 queues 695 us, 16 581, 32 388, 64 320, 128 ~310, 256 296, 512 316; static 337)   // counters the waves of dfire_bm_cull draw their items from
 constexpr int kBmCullHitTiles = 4;              // hit list of a dfire_bm_cull wave: room for this many poses that reach every receptor tile
 __host__ __device__ inline int bm_cull_hit_cap(int n_rt) { return kBmCullHitTiles * n_rt > 192 ? kBmCullHitTiles * n_rt : 192; }   // (a flush costs one atomic per tile pair)
 __host__ __device__ inline size_t bm_cull_wave_lds(int n_rt) { return ((size_t)bm_cull_hit_cap(n_rt) * 12 + (size_t)n_rt * 8 + 15) / 16 * 16; }
@@ -187,8 +188,28 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     const size_t n_items = (rows + kBmCullPoses - 1) / kBmCullPoses * (size_t)n_lt;
     const float ubound = T->m.ubound, pad = T->m.box_pad;
     const int bj = lane & 7;
-    // the waves of a workgroup are independent (no barrier); a wave walks items until the launch's rows are done
-    for (size_t item = (size_t)blockIdx.x * kBmCullWaves + wave; item < n_items; item += (size_t)gridDim.x * kBmCullWaves) {
+    // The waves of a workgroup are independent (no barrier).  Items differ several times over in length (a ligand tile at
+    // the interface lists twenty receptor tiles, one on the far side none), and a fixed stride through the items gives a wave
+    // only the tiles of one residue class: handed out statically the waves of a 1k4c launch lived 129 to 332 us.  So a wave
+    // DRAWS its items, one ahead, from one of up to kBmCullQueues counters (few counters serialise: 53 k atomics over 8
+    // addresses took twice the kernel's time): queue q holds a contiguous range of items (every ligand tile equally often) and
+    // is served by the workgroups q, q + Q, ...
+    if (n_items == 0) return;   // (a quiet GSO step)
+    const uint32_t n_queues = gridDim.x < (unsigned)kBmCullQueues ? gridDim.x : (uint32_t)kBmCullQueues;
+    const uint32_t queue = blockIdx.x % n_queues;
+    const size_t per_queue = (n_items + n_queues - 1) / n_queues;
+    const size_t queue_first = (size_t)queue * per_queue;
+    const size_t queue_end = queue_first + per_queue < n_items ? queue_first + per_queue : n_items;
+    uint32_t *queue_counter = T->job_count + kBmCounters + queue;
+    auto draw = [&]() {
+        uint32_t ticket = 0;
+        if (lane == 0) ticket = atomicAdd(queue_counter, 1u);
+        return ticket;   // lane 0, on its way
+    };
+    uint32_t next_ticket = draw();
+    for (;;) {
+    const size_t item = queue_first + (uint32_t)__builtin_amdgcn_readfirstlane((int)next_ticket);
+    if (item >= queue_end) break;
     const size_t group = item / (unsigned)n_lt;
     const int lt = (int)(item % (unsigned)n_lt);
     const size_t listed0 = group * kBmCullPoses;
@@ -352,6 +373,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         if (COUNT && lane == 0) T->tile_tested[pose * (size_t)n_lt + lt] = tested;
         if (lane == g) my_nvis = n_hits - first_hit;
     }
+    next_ticket = draw();   // (here, not at the item's start: memory operations return in order, and the item's loads would wait for it)
     flush();
     if (my_pose >= 0) T->vis_count[(size_t)my_pose * n_lt + lt] = my_nvis;
     }

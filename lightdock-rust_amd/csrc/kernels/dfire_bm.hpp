@@ -70,7 +70,8 @@ constexpr int kBmPartEntries = 1024;         // entries of a tile pair in one jo
 constexpr int kBmQueue = 128;                // per wave: pairs waiting for the exact path
 constexpr double kBmFixScale = 1099511627776.0;  // 2^40: fixed-point units of the exact path's sum
 constexpr int kBmCounters = 8;               // words behind tp_count, zeroed per launch: (tile pair, part) pairs listed, jobs drawn, entries per
-                                             // part, jobs listed, workgroups of dfire_bm_order done
+                                             // part, jobs listed; behind them kBmCullQueueWords item counters of dfire_bm_cull
+constexpr int kBmCullQueueWords = 256;
 constexpr int kBmCostClasses = 80;           // jobs are drawn in classes of estimated length, longest first
 
 struct BmModel {

@@ -912,7 +912,7 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         const size_t w = (size_t)lane;   // workspace set
         t.first = off;
         t.n_poses = std::min(cap, n - off);
-        t.tp_count = static_cast<uint32_t *>(ws_bm_tp_count_.ptr) + w * (tile_pairs + kBmCounters);
+        t.tp_count = static_cast<uint32_t *>(ws_bm_tp_count_.ptr) + w * (tile_pairs + kBmCounters + kBmCullQueueWords);
         t.job_count = t.tp_count + tile_pairs;
         t.job_next = t.tp_count + tile_pairs + 1;
         t.jobs = static_cast<uint32_t *>(ws_bm_jobs_.ptr) + w * jobs_per_lane;
@@ -923,7 +923,7 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         t.ent_rt = static_cast<float *>(ws_bm_ent_rt_.ptr) + w * tile_pairs * cap * 12;
         t.ent_partial = static_cast<double *>(ws_bm_ent_partial_.ptr) + w * tile_pairs * kBmJobRows * cap;
         t.ent_count = counts ? static_cast<uint32_t *>(ws_bm_ent_count_.ptr) + w * tile_pairs * kBmJobRows * cap : nullptr;
-        hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + kBmCounters) * sizeof(uint32_t), st), "hipMemsetAsync(tile pair counts)");
+        hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + kBmCounters + kBmCullQueueWords) * sizeof(uint32_t), st), "hipMemsetAsync(tile pair counts)");
         hip_check(launch_bm_pose(t, st), "launch dfire_bm_pose");
         hip_check(launch_bm_cull(t, st), "launch dfire_bm_cull");
         hip_check(launch_bm_pairs(t, st), "launch dfire_bm_pairs");
@@ -1039,7 +1039,7 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         const size_t n = n_poses, n_lt = (size_t)bm_.lig.n_tiles, n_rt = (size_t)bm_.rec_n_tiles, tile_pairs = n_lt * n_rt;
         const size_t cap = bm_pass_poses(n) * 2;   // two passes in flight (run_bm), each with its own entry workspace
         ws_bm_rt_.reserve(n * 12 * sizeof(float));
-        ws_bm_tp_count_.reserve(2 * (tile_pairs + kBmCounters) * sizeof(uint32_t));   // + the launch's counters
+        ws_bm_tp_count_.reserve(2 * (tile_pairs + kBmCounters + kBmCullQueueWords) * sizeof(uint32_t));   // + the launch's counters
         ws_bm_jobs_.reserve(2 * (tile_pairs * (cap / 2 / 64 + 1)) * 2 * sizeof(uint32_t));   // at most entries / 64 + tile pairs parts
         ws_bm_job_cost_.reserve(2 * (tile_pairs * (cap / 2 / 64 + 1)) * kBmJobRows * sizeof(uint32_t));
         ws_bm_job_order_.reserve(2 * (tile_pairs * (cap / 2 / 64 + 1)) * kBmJobRows * sizeof(uint32_t));
