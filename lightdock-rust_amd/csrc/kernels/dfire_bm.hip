@@ -557,6 +557,7 @@ struct BmWaveShared {
     unsigned char row_bits[kBmPartEntries];        // per entry of the job: which of the 8 blocks (a, .) it holds
     unsigned short items[kBmPartEntries + 64];     // the entries that hold the current block (| 0x8000: its first block of the row)
     uint32_t queue[kBmQueue];                      // pairs for the exact path
+    float4 lig_local[kBmLig];                      // the job's ligand atoms: local coordinates, w = 1 for a real atom
 };
 struct BmShared {
     unsigned char lut[kBmLutBytes];   // indexed from the far end: cell' = floor(kBmCellZero + 1/2 - 64 d2), everything further reads cell' 0
@@ -670,14 +671,9 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
         dbg_jobs++;
 
         // the ligand subtile's local coordinates (uniform)
-        float Lx[kBmLig], Ly[kBmLig], Lz[kBmLig];
-        bool Lreal[kBmLig];
-#pragma unroll
-        for (int i = 0; i < kBmLig; i++) {
-            const float4 v = reinterpret_cast<const float4 *>(T->m.lig_local)[ls * 8 + la0 + i];
-            Lx[i] = v.x; Ly[i] = v.y; Lz[i] = v.z;
-            Lreal[i] = v.w != 0.f;
-        }
+        // (kept in LDS, read back per batch as broadcasts: 24 wave-uniform values in vector registers for the whole job are what
+        // pushed the block set-up into scratch)
+        if (lane < kBmLig) WS.lig_local[lane] = reinterpret_cast<const float4 *>(T->m.lig_local)[ls * 8 + la0 + lane];
         // table rows of a block -> LDS: kBmCubeRows * 11 pieces of 16 bytes, one LDS-DMA instruction per KiB
         constexpr int kPieces = kBmCubeRows * 11, kDma = (kPieces + 63) / 64;
         uint32_t src_lig[kDma];
@@ -794,7 +790,8 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
 #pragma unroll
                 for (int i = 0; i < kBmLig; i++) {
                     float lx, ly, lz;
-                    bm_apply(A, Lx[i], Ly[i], Lz[i], lx, ly, lz);
+                    const float4 L = WS.lig_local[i];
+                    bm_apply(A, L.x, L.y, L.z, lx, ly, lz);
                     lxy[i] = v2f{lx, ly};
                     lz2[i] = v2f{lz, __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz))};
                 }
@@ -839,7 +836,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                     for (int s8 = 0; s8 < 8; s8++) {
                         acc += tv[2 * s8];
                         acc += tv[2 * s8 + 1];
-                        if (COUNT && Lreal[(g * 8 + s8) % kBmLig])
+                        if (COUNT && WS.lig_local[(g * 8 + s8) % kBmLig].w != 0.f)
                             cnt += (w[2 * s8] != 0u && w[2 * s8] < kBmFlagged ? 1u : 0u) + (w[2 * s8 + 1] != 0u && w[2 * s8 + 1] < kBmFlagged ? 1u : 0u);
                         const uint32_t m2 = w[2 * s8] > w[2 * s8 + 1] ? w[2 * s8] : w[2 * s8 + 1];
                         wm = wm > m2 ? wm : m2;
