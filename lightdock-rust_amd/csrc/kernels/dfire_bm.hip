@@ -47,12 +47,6 @@ __host__ __device__ inline int bm_gather_chunks(int n_lt, int n_rt) {
 }
 constexpr float kBmBoxCut = 14400.0f * 1.00005f;  // (8 * 15 A)^2 in record units, padded for the rounding of the box test
 
-__device__ __forceinline__ uint32_t bm_cvt_u32(float f) {  // v_cvt_u32_f32 saturates: negative and NaN -> 0
-    uint32_t r;
-    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
-    return r;
-}
-
 // listed row -> pose row, or -1 beyond the list of this launch / inactive
 __device__ __forceinline__ long long bm_pose_of(BmArgs *T, size_t listed) {
     if (T->pose_count != nullptr && T->first + listed >= (size_t)*T->pose_count) return -1;
@@ -803,18 +797,34 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                 constexpr int kGroups = kBmLig / 2;
                 auto codes_of_group = [&](int g, uint32_t (&w)[16]) {
 #pragma unroll
-                    for (int s8 = 0; s8 < 8; s8++) {
+                    for (int s8 = 0; s8 < 8; s8 += 2) {
+                        static_assert(kBmLig == 8, "the two steps of a pair share the receptor record");
                         const int t = g * 8 + s8, q = t / kBmLig, i = t % kBmLig;
-                        // D = Rs - l2; D = fma(Rz, lz, D); D = fma(Ry, ly, D); D = fma(Rx, lx, D), both halves: written out
-                        // because the compiler duplicates the broadcast operands into register pairs (32 moves a group)
-                        v2f D;
-                        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(D) : "v"(Rs[q]), "v"(lz2[i]));
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(D) : "v"(Rz[q]), "v"(lz2[i]));
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(D) : "v"(Ry[q]), "v"(lxy[i]));
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(D) : "v"(Rx[q]), "v"(lxy[i]));
-                        const uint32_t c0 = bm_cvt_u32(D.x), c1 = bm_cvt_u32(D.y);
+                        // Two steps (ligand atoms i, i + 1 against the receptor record q) as ONE block of instructions:
+                        //   D = Rs - l2; D = fma(Rz, lz, D); D = fma(Ry, ly, D); D = fma(Rx, lx, D), both halves; cell = (u32)D
+                        // Written out because the compiler duplicates the broadcast operands into register pairs (32 moves a
+                        // group) instead of using op_sel; as one block because it guards every separate asm statement with an
+                        // s_nop (128 per batch); the two dependent chains interleaved.
+                        v2f D0, D1;
+                        uint32_t c0, c1, c2, c3;
+                        asm("v_pk_add_f32 %[d0], %[rs], %[za] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                            "v_pk_add_f32 %[d1], %[rs], %[zb] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                            "v_pk_fma_f32 %[d0], %[rz], %[za], %[d0] op_sel_hi:[1,0,1]\n\t"
+                            "v_pk_fma_f32 %[d1], %[rz], %[zb], %[d1] op_sel_hi:[1,0,1]\n\t"
+                            "v_pk_fma_f32 %[d0], %[ry], %[xa], %[d0] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                            "v_pk_fma_f32 %[d1], %[ry], %[xb], %[d1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                            "v_pk_fma_f32 %[d0], %[rx], %[xa], %[d0] op_sel_hi:[1,0,1]\n\t"
+                            "v_pk_fma_f32 %[d1], %[rx], %[xb], %[d1] op_sel_hi:[1,0,1]"
+                            : [d0] "=&v"(D0), [d1] "=&v"(D1)
+                            : [rs] "v"(Rs[q]), [rz] "v"(Rz[q]), [ry] "v"(Ry[q]), [rx] "v"(Rx[q]), [za] "v"(lz2[i]), [xa] "v"(lxy[i]),
+                              [zb] "v"(lz2[i + 1]), [xb] "v"(lxy[i + 1]));
+                        // (v_cvt_u32_f32 saturates: negative and NaN -> 0)
+                        asm("v_cvt_u32_f32 %0, %4\n\tv_cvt_u32_f32 %1, %5\n\tv_cvt_u32_f32 %2, %6\n\tv_cvt_u32_f32 %3, %7"
+                            : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3) : "v"(D0.x), "v"(D0.y), "v"(D1.x), "v"(D1.y));
                         w[2 * s8] = S.lut[c0];
                         w[2 * s8 + 1] = S.lut[c1];
+                        w[2 * s8 + 2] = S.lut[c2];
+                        w[2 * s8 + 3] = S.lut[c3];
                     }
                 };
                 // (computing the codes of group g + 1 while the table values of group g are on their way was tried: the second
