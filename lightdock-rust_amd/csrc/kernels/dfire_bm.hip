@@ -289,6 +289,19 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         if (n_hits + (uint32_t)n_rt > (uint32_t)hit_cap) flush();
         const uint32_t first_hit = n_hits;
         if (lane == g) my_first = first_hit;
+        // the hits of one ballot of receptor tiles, lane-distributed, written to the list together (one LDS store per lane
+        // instead of a scalar branch, five register moves and two stores per hit)
+        uint32_t held = 0;                  // wave-uniform
+        unsigned long long held_mask = 0ull;
+        uint32_t held_key = 0;
+        auto put_held = [&]() {
+            if ((uint32_t)lane < held) {
+                s_hmask[n_hits + (uint32_t)lane] = held_mask;
+                s_hkey[n_hits + (uint32_t)lane] = (unsigned short)held_key;
+            }
+            n_hits += held;
+            held = 0;
+        };
         {   // A tile whose bounding sphere stays beyond the cutoff of every receptor tile's box has nothing to list (most tiles
             // of a large ligand, in most poses): one point posed and one test per receptor tile instead of 64 atoms posed,
             // their boxes and the box tests.
@@ -353,16 +366,17 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                 for (int k = 0; k < 4; k++) {
                     if (k >= nk) break;
                     const unsigned long long smask = __ballot(box_gap2(sub, nb[k]) <= kBmBoxCut);  // bit = ligand subtile (lane >> 3) * 8 + receptor subtile
-                    if (smask) {
-                        if (lane == 0) {
-                            s_hmask[n_hits] = smask;
-                            s_hkey[n_hits] = (unsigned short)(g << 8 | RTs[k]);
+                    if (smask) {   // hit `held` of this ballot stays in lane `held` until the ballot's tiles are done
+                        if (lane == (int)held) {
+                            held_mask = smask;
+                            held_key = (uint32_t)(g << 8 | RTs[k]);
                         }
-                        n_hits++;
+                        held++;
                     }
                     if (COUNT) tested += (uint32_t)__popcll(smask);
                 }
             }
+            put_held();   // (a ballot's 64 receptor tiles make at most 64 hits)
         }
         if (COUNT && lane == 0) T->tile_tested[pose * (size_t)n_lt + lt] = tested;
         if (lane == g) my_nvis = n_hits - first_hit;
