@@ -329,17 +329,13 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         // box + 16 A): it joins no box; the pairs it still meets inside blocks of its subtile read "miss", as they must.
         BoxRegs sub = lane_box(valid && inside, fx, fy, fz);
         box_reduce8(sub);
-        BoxRegs whole = sub;
-        box_reduce64_from8(whole);
         {   // widen: the f32 positions are within box_pad of the exactly posed ones
-            auto widen = [pad](BoxRegs &b) {
-                box_widen(b);
-                b.lox -= pad; b.loy -= pad; b.loz -= pad;
-                b.hix += pad; b.hiy += pad; b.hiz += pad;
-            };
-            widen(sub);
-            widen(whole);
+            box_widen(sub);
+            sub.lox -= pad; sub.loy -= pad; sub.loz -= pad;
+            sub.hix += pad; sub.hiy += pad; sub.hiz += pad;
         }
+        BoxRegs whole = sub;   // (widening is monotone: the union of the widened subtile boxes IS the widened tile box)
+        box_reduce64_from8(whole);
         whole.lox = lane63_f32(whole.lox); whole.loy = lane63_f32(whole.loy); whole.loz = lane63_f32(whole.loz);
         whole.hix = lane63_f32(whole.hix); whole.hiy = lane63_f32(whole.hiy); whole.hiz = lane63_f32(whole.hiz);
 
