@@ -961,15 +961,18 @@ def _random_protein_pdb(path, n_atoms, seed, box):
     _write_pdb(path, atoms)
 
 
-def test_receptor_larger_than_one_ballot(pkg, orc, table, tmp_path):
+@pytest.mark.parametrize("n_rec,box", [(4700, 30.0), (9000, 38.0)])
+def test_receptor_larger_than_one_ballot(pkg, orc, table, tmp_path, n_rec, box):
     """More than 64 receptor tiles (> 4096 atoms: the tile-box ballot loops) and a ligand that is
-    not a multiple of 64, against the oracle and the all-pairs kernel."""
+    not a multiple of 64, against the oracle and the all-pairs kernel.  141 tiles (9000 atoms) also take the culling
+    kernel's LDS (receptor boxes + hit lists) past 64 KB, i.e. through hipFuncSetAttribute."""
     rec, lig = str(tmp_path / "big_rec.pdb"), str(tmp_path / "big_lig.pdb")
-    _random_protein_pdb(rec, 4700, 1, 30.0)
+    _random_protein_pdb(rec, n_rec, 1, box)
     _random_protein_pdb(lig, 333, 2, 8.0)
     cpu = orc.Scorer("dfire", rec, lig, rec_active=["A.LEU.2", "A.TRP.5"], lig_active=["A.ALA.1"], potential=table)
     hip = pkg.Scorer.from_pdb("dfire", rec, lig, rec_active=["A.LEU.2", "A.TRP.5"], lig_active=["A.ALA.1"], potential=table)
-    assert hip.num_atoms(0) == 4700 and hip.num_atoms(1) == 333
+    assert hip.num_atoms(0) == n_rec and hip.num_atoms(1) == 333
+    assert hip.kernel_info()["pair_kernel_name"] == "dfire_bm_pairs"
     poses = pkg.synth.swarm(24, seed=9)
     poses[:, :3] *= 0.8
     want = cpu.energy_rows(poses)
