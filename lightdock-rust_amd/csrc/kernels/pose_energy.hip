@@ -366,6 +366,13 @@ __global__ __launch_bounds__(kBlockThreads) void pose_energy_finish(const Finish
         s1 += __shfl_xor(s1, d);
         cnt += __shfl_xor(cnt, d);
     }
+    // membrane beads (src/scoring.rs:38-47): the pose's eight lanes share the scan, the count is an integer
+    const uint32_t *rwords = F.flags + (live ? pose : 0) * (size_t)(F.rec_flag_words + F.lig_flag_words);
+    int beads = 0;
+    if (live)
+        for (int k = sub; k < F.tail.n_membrane; k += kFinishLanes) beads += flag_set(rwords, F.tail.membrane_slots[k]) ? 1 : 0;
+    if (F.tail.n_membrane > 0)
+        for (int d = 1; d < kFinishLanes; d <<= 1) beads += __shfl_xor(beads, d);
     if (!live || sub != 0) return;
     double score;
     if (F.method == 0) {
@@ -374,14 +381,11 @@ __global__ __launch_bounds__(kBlockThreads) void pose_energy_finish(const Finish
         const double total_elec = s0 * 332.0 / 4.0;  // src/dna.rs:513
         score = (total_elec + s1) * -1.0;            // src/dna.rs:514
     }
-    const uint32_t *rwords = F.flags + pose * (size_t)(F.rec_flag_words + F.lig_flag_words);
     const uint32_t *lwords = rwords + F.rec_flag_words;
     const double pr = satisfied_fraction(rwords, F.tail.n_rec_groups, F.tail.rec_group_offsets, F.tail.rec_group_slots);
     const double pl = satisfied_fraction(lwords, F.tail.n_lig_groups, F.tail.lig_group_offsets, F.tail.lig_group_slots);
     double penalty = 0.0;
     if (F.tail.n_membrane > 0) {  // src/scoring.rs:38-47, src/dfire.rs:355-359
-        int beads = 0;
-        for (int k = 0; k < F.tail.n_membrane; k++) beads += flag_set(rwords, F.tail.membrane_slots[k]) ? 1 : 0;
         const double intersection = (double)beads / (double)F.tail.n_membrane;
         if (intersection > 0.0) penalty = 999.0 * intersection;
     }
