@@ -130,6 +130,11 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
         o[9] = (float)(k * 2.0 * (y * z + w * x));
         o[10] = (float)(k * (w * w - x * x - y * y + z * z));
         o[11] = (float)(kBmKappa * (tz - T->m.cz));
+        {   // the pose's interface-flag words (the exact path sets bits, pose_energy_finish reads them)
+            const int words = T->m.rec_flag_words + T->m.lig.flag_words;
+            uint32_t *f = T->flags + pose * (size_t)words;
+            for (int k = 0; k < words; k++) f[k] = 0u;
+        }
         if (T->exact_fix) T->exact_fix[pose] = 0;
         if (T->exact_count) T->exact_count[pose] = 0;
         if (T->exact_pairs) T->exact_pairs[pose] = 0;

@@ -1098,7 +1098,8 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
     p.count_partial = d_pair_counts ? static_cast<uint32_t *>(ws_counts_.ptr) : nullptr;
 
     const size_t words = (size_t)(p.rec.flag_words + p.lig.flag_words);
-    if (words > 0) hip_check(hipMemsetAsync(p.flags, 0, n * words * sizeof(uint32_t), stream_), "hipMemsetAsync(flags)");
+    // (the block-major path clears a pose's flag words in dfire_bm_pose: one launch less per step)
+    if (words > 0 && !use_bm_) hip_check(hipMemsetAsync(p.flags, 0, n * words * sizeof(uint32_t), stream_), "hipMemsetAsync(flags)");
     const bool timing = timing_ && !capturing_;
     if (timing) {
         if (events_used_ == events_.size()) {
