@@ -9,8 +9,12 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
+#include <cstdlib>
+#include <type_traits>
 
 #include "dfire_device.hpp"
+#include "dfire_bm_batch.inc"
 
 namespace ld {
 
@@ -33,7 +37,7 @@ constexpr int kBmCullPoses = LD_BM_CULL_POSES;   // poses a wave of dfire_bm_cul
 constexpr int kBmCullQueues = kBmCullQueueWords;   // (1k4c: 8 queues 695 us, 16 581, 32 388, 64 320, 128 ~310, 256 296, 512 316; static 337)   // counters the waves of dfire_bm_cull draw their items from
 constexpr int kBmCullHitTiles = 4;              // hit list of a dfire_bm_cull wave: room for this many poses that reach every receptor tile
 __host__ __device__ inline int bm_cull_hit_cap(int n_rt) { return kBmCullHitTiles * n_rt > 192 ? kBmCullHitTiles * n_rt : 192; }   // (a flush costs one atomic per tile pair)
-__host__ __device__ inline size_t bm_cull_wave_lds(int n_rt) { return ((size_t)bm_cull_hit_cap(n_rt) * 12 + (size_t)n_rt * 8 + 15) / 16 * 16; }
+__host__ __device__ inline size_t bm_cull_wave_lds(int n_rt) { return ((size_t)bm_cull_hit_cap(n_rt) * 14 + (size_t)n_rt * 8 + 15) / 16 * 16; }
 // dfire_bm_gather: threads per pose = span (a power of two covering the ligand's tiles) x chunks (up to 64 threads per pose)
 __host__ __device__ inline int bm_gather_span(int n_lt) {
     int span = 1;
@@ -47,7 +51,7 @@ __host__ __device__ inline int bm_gather_chunks(int n_lt, int n_rt) {
 }
 constexpr float kBmBoxCut = 14400.0f * 1.00005f;  // (8 * 15 A)^2 in record units, padded for the rounding of the box test
 
-// listed row -> pose row, or -1 beyond the list of this launch / inactive
+// row of the pass -> pose row, or -1 beyond the list of this launch / inactive
 __device__ __forceinline__ long long bm_pose_of(BmArgs *T, size_t listed) {
     if (T->pose_count != nullptr && T->first + listed >= (size_t)*T->pose_count) return -1;
     const size_t pose = T->pose_list ? (size_t)T->pose_list[T->first + listed] : T->first + listed;
@@ -72,16 +76,6 @@ __device__ __forceinline__ void bm_apply(const Affine &A, float x, float y, floa
     uy = __builtin_fmaf(A.r10, x, __builtin_fmaf(A.r11, y, __builtin_fmaf(A.r12, z, A.ty)));
     uz = __builtin_fmaf(A.r20, x, __builtin_fmaf(A.r21, y, __builtin_fmaf(A.r22, z, A.tz)));
 }
-__device__ __forceinline__ TiledLigand bm_ligand(BmArgs *T) {
-    TiledLigand l;
-    l.n_real = T->m.lig.n_real;
-    l.n_tiles = T->m.lig.n_tiles;
-    l.x = T->m.lig.x;
-    l.y = T->m.lig.y;
-    l.z = T->m.lig.z;
-    return l;
-}
-
 __device__ __forceinline__ ExactCtx bm_exact_ctx(BmArgs *T, size_t pose) {
     ExactCtx ex;
     ex.rx = T->m.rec_x;
@@ -97,13 +91,13 @@ __device__ __forceinline__ ExactCtx bm_exact_ctx(BmArgs *T, size_t pose) {
     ex.step4 = T->m.bin_step;  // already 4 * step (scorer.cpp)
     ex.table = T->m.table;
     ex.iface_scaled = T->m.iface_scaled;
-    ex.pose_flags = T->flags + pose * (size_t)(T->m.rec_flag_words + T->m.lig.flag_words);
+    ex.pose_flags = T->flags + pose * (size_t)(T->m.rec_flag_words + T->m.lig.flag_words);   // (by pose: pose_energy_finish reads them)
     ex.rec_flag_words = T->m.rec_flag_words;
     return ex;
 }
 
 // ---------------------------------------------------------------------------------------------
-// dfire_bm_pose: pose row -> f32 affine map into the record frame.  v' = q v q^-1 + t (src/qt.rs:48-61) is the
+// dfire_bm_pose: pose row -> f32 affine map into the record frame, [row of the pass][12].  v' = q v q^-1 + t (src/qt.rs:48-61) is the
 // rotation matrix of q / |q|; computed in f64, rounded once.  Its error is part of eps (dfire_bm_error_bound).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_arguments) {
@@ -117,7 +111,7 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
         const double tx = row[0], ty = row[1], tz = row[2], w = row[3], x = row[4], y = row[5], z = row[6];
         const double n2 = w * w + x * x + y * y + z * z;
         const double k = kBmKappa / n2;
-        float *o = T->rt + pose * 12;
+        float *o = T->rt + listed * 12;
         o[0] = (float)(k * (w * w + x * x - y * y - z * z));
         o[1] = (float)(k * 2.0 * (x * y - w * z));
         o[2] = (float)(k * 2.0 * (x * z + w * y));
@@ -135,9 +129,8 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
             uint32_t *f = T->flags + pose * (size_t)words;
             for (int k = 0; k < words; k++) f[k] = 0u;
         }
-        if (T->exact_fix) T->exact_fix[pose] = 0;
-        if (T->exact_count) T->exact_count[pose] = 0;
-        if (T->exact_pairs) T->exact_pairs[pose] = 0;
+        if (T->exact_fix) T->exact_fix[listed] = 0;
+        if (T->exact_pairs) T->exact_pairs[listed] = 0;
     }
 }
 
@@ -147,11 +140,11 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
 // tile: ONE atomic per tile pair for all the poses of the wave (the lists of a small complex have few heads: one
 // returning atomic per pose and tile pair serialises on them), then the entries.
 // ---------------------------------------------------------------------------------------------
-// bit (a * kBmHalves + h): the mask holds a block of ligand subtile a in the h-th part of its row
+// bit a: the mask holds a block of ligand subtile a
 __device__ __forceinline__ uint32_t bm_rows_of(unsigned long long mask) {
     uint32_t rows = 0;
 #pragma unroll
-    for (int k = 0; k < 8 * kBmHalves; k++) rows |= ((mask >> (k * (8 / kBmHalves))) & ((1ull << (8 / kBmHalves)) - 1ull)) ? 1u << k : 0u;
+    for (int k = 0; k < 8; k++) rows |= ((mask >> (k * 8)) & 0xffull) ? 1u << k : 0u;
     return rows;
 }
 
@@ -174,8 +167,8 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     unsigned long long *s_hmask = reinterpret_cast<unsigned long long *>(s_wave);          // [hit_cap]
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_hmask + hit_cap);                      // [n_rt]
     uint32_t *s_base = s_cnt + n_rt;                                                        // [n_rt]
-    unsigned short *s_hkey = reinterpret_cast<unsigned short *>(s_base + n_rt);             // [hit_cap]: pose of the wave << 8 | receptor tile
-    unsigned short *s_hrank = s_hkey + hit_cap;                                             // [hit_cap]: place among the wave's hits of that tile pair
+    uint32_t *s_hkey = s_base + n_rt;                                                       // [hit_cap]: pose of the wave << 16 | receptor tile
+    unsigned short *s_hrank = reinterpret_cast<unsigned short *>(s_hkey + hit_cap);         // [hit_cap]: place among the wave's hits of that tile pair
     {
         static_assert(sizeof(TiledBox) == 32, "two 16-byte pieces");
         const uint4 *src_sub = reinterpret_cast<const uint4 *>(T->m.rec_sub), *src_tile = reinterpret_cast<const uint4 *>(T->m.rec_tile);
@@ -222,11 +215,12 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     if (lane < n_rt) my_tile = s_tile[lane];
 
     // the item's poses and their affine maps: lane g loads those of pose g, all in flight together
-    long long my_pose = -1;
+    long long my_pose = -1;   // (only its sign is used: the workspace of a pass goes by row)
+    const uint32_t my_row = (uint32_t)(listed0 + lane);
     float4 my_a0 = float4{0.f, 0.f, 0.f, 0.f}, my_a1 = my_a0, my_a2 = my_a0;
     if (lane < kBmCullPoses && listed0 + lane < rows) my_pose = bm_pose_of(T, listed0 + lane);
     if (my_pose >= 0) {
-        const float4 *ap = reinterpret_cast<const float4 *>(T->rt + (size_t)my_pose * 12);
+        const float4 *ap = reinterpret_cast<const float4 *>(T->rt + (size_t)my_row * 12);
         my_a0 = ap[0];
         my_a1 = ap[1];
         my_a2 = ap[2];
@@ -242,12 +236,13 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     uint32_t my_first = 0, my_nvis = 0;  // lane g: where pose g's hits start in the list; how many it has
     // ---- the list -> entries.  One LDS atomic per hit (its place among the wave's hits of the tile pair), ONE global atomic per
     // tile pair for the whole wave (the lists of a small complex have few heads: one returning atomic per pose and tile pair
-    // serialises on them), then lane = hit writes the entry.
+    // serialises on them), then lane = hit writes the entry: 12 bytes (the pair kernel reads the pose's affine map from the
+    // [row][12] table, which stays in L2; a copy per entry was 48 more bytes written here and read per item from HBM there).
     auto flush = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (int k = lane; k < n_rt; k += 64) s_cnt[k] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (uint32_t h = (uint32_t)lane; h < n_hits; h += 64) s_hrank[h] = (unsigned short)atomicAdd(&s_cnt[s_hkey[h] & 0xffu], 1u);
+        for (uint32_t h = (uint32_t)lane; h < n_hits; h += 64) s_hrank[h] = (unsigned short)atomicAdd(&s_cnt[s_hkey[h] & 0xffffu], 1u);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (int k = lane; k < n_rt; k += 64) {
             const uint32_t total = s_cnt[k];
@@ -258,24 +253,17 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
             const uint32_t h = h0 + (uint32_t)lane;
             const bool act = h < n_hits;
             const uint32_t key = act ? s_hkey[h] : 0u;
-            const int g = (int)(key >> 8), RT = (int)(key & 0xffu);
-            // what lane g holds about pose g (every lane takes part in the shuffles)
-            const uint32_t pose = (uint32_t)__shfl((int)(uint32_t)my_pose, g, 64);
+            const int g = (int)(key >> 16), RT = (int)(key & 0xffffu);
+            // what lane g holds about pose g (every lane takes part in the shuffle)
             const uint32_t first = (uint32_t)__shfl((int)my_first, g, 64);
-            const float4 a0 = float4{__shfl(my_a0.x, g, 64), __shfl(my_a0.y, g, 64), __shfl(my_a0.z, g, 64), __shfl(my_a0.w, g, 64)};
-            const float4 a1 = float4{__shfl(my_a1.x, g, 64), __shfl(my_a1.y, g, 64), __shfl(my_a1.z, g, 64), __shfl(my_a1.w, g, 64)};
-            const float4 a2 = float4{__shfl(my_a2.x, g, 64), __shfl(my_a2.y, g, 64), __shfl(my_a2.z, g, 64), __shfl(my_a2.w, g, 64)};
             if (act) {
                 const unsigned long long mask = s_hmask[h];
                 const uint32_t idx = s_base[RT] + s_hrank[h];
                 const size_t at = ((size_t)lt * n_rt + RT) * T->cap + idx;
-                T->ent_pose[at] = pose;
+                const uint32_t row = (uint32_t)listed0 + (uint32_t)g;
+                T->ent_row[at] = row;
                 T->ent_mask[at] = mask;
-                float4 *ap = reinterpret_cast<float4 *>(T->ent_rt) + at * 3;   // (what a pair batch poses the entry with)
-                ap[0] = a0;
-                ap[1] = a1;
-                ap[2] = a2;
-                T->vis_entry[((size_t)pose * n_lt + lt) * (size_t)n_rt + (h - first)] =
+                T->vis_entry[((size_t)row * n_lt + lt) * (size_t)n_rt + (h - first)] =
                     (unsigned long long)RT << 48 | (unsigned long long)bm_rows_of(mask) << 32 | idx;
             }
         }
@@ -289,7 +277,6 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         pose_of[g] = (long long)((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_pose, g) |
                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)my_pose >> 32), g) << 32);
         if (pose_of[g] < 0) continue;
-        const size_t pose = (size_t)pose_of[g];
         const Affine A = affine_of(g);
         if (n_hits + (uint32_t)n_rt > (uint32_t)hit_cap) flush();
         const uint32_t first_hit = n_hits;
@@ -302,7 +289,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         auto put_held = [&]() {
             if ((uint32_t)lane < held) {
                 s_hmask[n_hits + (uint32_t)lane] = held_mask;
-                s_hkey[n_hits + (uint32_t)lane] = (unsigned short)held_key;
+                s_hkey[n_hits + (uint32_t)lane] = held_key;
             }
             n_hits += held;
             held = 0;
@@ -322,7 +309,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                 any_near = __ballot(base + lane < n_rt && gx * gx + gy * gy + gz * gz <= reach * reach) != 0ull;
             }
             if (!any_near) {
-                if (COUNT && lane == 0) T->tile_tested[pose * (size_t)n_lt + lt] = 0;
+                if (COUNT && lane == 0) T->tile_tested[(listed0 + g) * (size_t)n_lt + lt] = 0;
                 continue;
             }
         }
@@ -370,7 +357,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                     if (smask) {   // hit `held` of this ballot stays in lane `held` until the ballot's tiles are done
                         if (lane == (int)held) {
                             held_mask = smask;
-                            held_key = (uint32_t)(g << 8 | RTs[k]);
+                            held_key = (uint32_t)(g << 16 | RTs[k]);
                         }
                         held++;
                     }
@@ -379,12 +366,12 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
             }
             put_held();   // (a ballot's 64 receptor tiles make at most 64 hits)
         }
-        if (COUNT && lane == 0) T->tile_tested[pose * (size_t)n_lt + lt] = tested;
+        if (COUNT && lane == 0) T->tile_tested[(listed0 + g) * (size_t)n_lt + lt] = tested;
         if (lane == g) my_nvis = n_hits - first_hit;
     }
     next_ticket = draw();   // (here, not at the item's start: memory operations return in order, and the item's loads would wait for it)
     flush();
-    if (my_pose >= 0) T->vis_count[(size_t)my_pose * n_lt + lt] = my_nvis;
+    if (my_pose >= 0) T->vis_count[(size_t)my_row * n_lt + lt] = my_nvis;
     }
 }
 
@@ -410,7 +397,7 @@ __global__ __launch_bounds__(1024) void dfire_bm_plan(const BmLaunch launch_argu
     if (mine) atomicAdd(&s_total, mine);
     __syncthreads();
     // about one (tile pair, part) pair per wave of the pair kernel, i.e. kBmJobRows jobs per wave
-    const uint32_t waves = (uint32_t)(T->pairs_groups > 0 ? T->pairs_groups : 256) * kBmWaves;
+    const uint32_t waves = (uint32_t)(T->pairs_groups > 0 ? T->pairs_groups : 256) * kBmWavesPerCu;
 #ifndef LD_BM_P_FACTOR
 #define LD_BM_P_FACTOR 4
 #endif
@@ -466,7 +453,7 @@ __global__ __launch_bounds__(1024) void dfire_bm_plan(const BmLaunch launch_argu
 // ---------------------------------------------------------------------------------------------
 constexpr int kBmOrderWaves = 16;
 __global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_census(const BmLaunch launch_arguments) {
-    static_assert(kBmJobRows == 8 && kBmHalves == 1 && kBmSplit == 1, "a job row is one byte of the block mask");
+    static_assert(kBmJobRows == 8, "a job row is one byte of the block mask");
     BmArgs *T = LD_BM_ARGS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -557,23 +544,27 @@ __global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_order(const BmLau
 }
 
 // ---------------------------------------------------------------------------------------------
-// dfire_bm_pairs: persistent workgroups (one per CU) of 8 independent waves; a wave draws jobs
+// dfire_bm_pairs: persistent workgroups (two per CU) of 4 independent waves; a wave draws jobs
 // (tile pair, part of its entries, ligand subtile a) and walks the job's 8 blocks (a, b), each with its 64 table
-// rows staged in the wave's own slice of LDS.  The waves share the cell LUT and nothing else: no barrier after set-up.
+// rows staged in the wave's own cube in LDS.  The waves share the cell LUT and nothing else: no barrier after set-up.
+// The batch code exists once per wave of the workgroup (switch on the wave number): the LDS address of a cube row is a
+// constant of the instruction that reads it, so a pair's table address is `code - 8`, no base to add.
 // ---------------------------------------------------------------------------------------------
 struct BmWaveShared {
-    unsigned char cube[kBmCubeBytes];
     unsigned char row_bits[kBmPartEntries];        // per entry of the job: which of the 8 blocks (a, .) it holds
     unsigned short items[kBmPartEntries + 64];     // the entries that hold the current block (| 0x8000: its first block of the row)
-    uint32_t queue[kBmQueue];                      // pairs for the exact path
-    float4 lig_local[kBmLig];                      // the job's ligand atoms: local coordinates, w = 1 for a real atom
+    unsigned short rows[kBmPartEntries];           // per entry of the job: its row of the pass (where its affine map is)
+    float4 lig_local[8];                           // the job's ligand atoms: local coordinates, w = 1 for a real atom
 };
 struct BmShared {
     unsigned char lut[kBmLutBytes];   // indexed from the far end: cell' = floor(kBmCellZero + 1/2 - 64 d2), everything further reads cell' 0
+    unsigned char cube[kBmWaves][kBmCubeBytes];   // (in front of the per-wave lists: every cube row within the 16-bit offset field of a DS instruction)
     BmWaveShared w[kBmWaves];
 };
+static_assert(sizeof(BmShared) * kBmGroupsPerCu <= 160 * 1024, "two workgroups per CU");
+static_assert(offsetof(BmShared, cube) + sizeof(unsigned char[kBmWaves][kBmCubeBytes]) < 65536, "cube rows are addressed by instruction offsets");
 
-// what a wave needs to evaluate queued pairs exactly
+// what a wave needs to evaluate queued items
 struct BmWaveCtx {
     size_t tp;       // tile pair
     int ls;          // ligand subtile (global)
@@ -581,64 +572,200 @@ struct BmWaveCtx {
     size_t lo;       // first entry of the job
 };
 
-// Queue item: entry (local to the job) | (i * 8 + j) << 10 | b << 16 | kBmFlagsOnly (the pair's table value is in the sum already:
-// only its interface flags are wanted)
-constexpr uint32_t kBmFlagsOnly = 1u << 19;
-template <bool COUNT>
-__device__ __noinline__ void bm_drain(BmArgs *T, const BmWaveCtx &W, const uint32_t *queue, uint32_t queued, int lane) {
-    for (uint32_t k = (uint32_t)lane; k < queued; k += 64) {
-        const uint32_t item = queue[k];
-        const size_t e = W.lo + (item & 1023u);
-        const int i = (int)((item >> 13) & 7u), j = (int)((item >> 10) & 7u), b = (int)((item >> 16) & 7u);
-        const int la = W.ls * 8 + i, ra = W.RT * 64 + b * 8 + j;
-        if (la >= T->m.lig.n_real || ra >= T->m.rec_n_real) continue;
-        const size_t pose = T->ent_pose[W.tp * T->cap + e];
-        const ExactCtx ex = bm_exact_ctx(T, pose);
-        const Vec3 p = pose_ligand_atom(bm_ligand(T), 0, 0, T->poses + pose * T->stride, la);
-        uint32_t cnt = 0;
-        const double v = exact_pair(ex, p, T->m.lig.tindex[la], la, ra, cnt);   // (sets the interface flags)
-        if (item & kBmFlagsOnly) continue;
-        // order-free: 2^-40 fixed point (the one place where a table value is rounded: below the noise of any f64 sum order)
-        const long long fix = __double2ll_rn(v * kBmFixScale);
-        if (fix != 0) atomicAdd(reinterpret_cast<unsigned long long *>(T->exact_fix + pose), (unsigned long long)fix);
-        if (COUNT) {
-            if (cnt) atomicAdd(T->exact_count + pose, cnt);
-            atomicAdd(T->exact_pairs + pose, 1u);
-        }
-    }
+// ---- the exact path.  A flagged cell reads its row's MARKER, (64 + i * 8 + j) << 50, instead of a table value.  After a
+// block's 64 adds the bits above 2^50 of a lane's sum are 0 (no flagged pair), 64 + pair (one: fourteen lanes in a
+// hundred) or at least 128 (several: four lanes in a thousand).  One flagged pair is named by the sum itself and goes
+// straight into the wave's list of pairs, a 64-bit item = entry of the pass | ligand atom << 32 | receptor atom << 48 that
+// needs nothing else of the job it came from: bm_exact_pairs evaluates the list between two jobs, a few hundred pairs at a
+// time, inlined (as a function of its own every call moved a hundred registers through scratch: a fifth of the kernel's
+// time), where little of the job loop's state is live.  With several flagged pairs the (entry, block) goes into a second list, and bm_recheck, at the
+// job's end, finds its flagged pairs again: lane = item, the block's 64 pairs once more by the batch's own f32 arithmetic
+// -- the same operations in the same order on the same operands, hence the same cells bit for bit.
+// bm_exact_pairs: lane = flagged pair: exact_pair (f64, the reference's operation order, dfire_device.hpp), its value added
+// to the pose's fixed-point sum by an atomic, its interface flags set.  The lists live in global memory (in practice a few
+// lines per wave that never leave the L2).
+#ifndef LD_BM_DRAIN_AT
+#define LD_BM_DRAIN_AT 256
+#endif
+constexpr int kBmDrainAt = LD_BM_DRAIN_AT;   // flagged pairs a wave collects before it evaluates them
+__device__ __forceinline__ unsigned long long bm_pair_item(size_t entry, int la, int ra) {
+    return (unsigned long long)entry | (unsigned long long)la << 32 | (unsigned long long)ra << 48;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pairs(const BmLaunch launch_arguments) {
+__device__ __forceinline__ void bm_exact_pairs(BmArgs *T, unsigned long long *queue, uint32_t n_pairs, int lane) {
+    // the wave reads back what it pushed itself: its stores are complete (through the write-through L1, in the XCD's L2), and
+    // the loads below go past the L1.  (An agent-scope release here writes the whole L2 back, on every drain of every wave:
+    // the launch took twice as long.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // Four pairs per lane and trip, phase by phase: the four items, then their rows, then everything the pairs read -- a
+    // pair is a chain of five dependent loads, and one at a time the chains were most of this function's time.
+    constexpr int U = 4;
+    const ExactCtx ex0 = bm_exact_ctx(T, 0);
+    const size_t flag_words = (size_t)(T->m.rec_flag_words + T->m.lig.flag_words);
+    for (uint32_t base = 0; base < n_pairs; base += 64 * U) {
+        unsigned long long item[U];
+        bool act[U];
+        int la[U], ra[U];
+        size_t row[U], pose[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t k = base + (uint32_t)(u * 64 + lane);
+            act[u] = k < n_pairs;
+            item[u] = act[u] ? __hip_atomic_load(queue + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;   // (past the L1)
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            la[u] = (int)((item[u] >> 32) & 0xffffu);
+            ra[u] = (int)(item[u] >> 48);
+            act[u] = act[u] && la[u] < T->m.lig.n_real && ra[u] < T->m.rec_n_real;   // (padding atoms of a block: nothing to add)
+            row[u] = act[u] ? T->ent_row[item[u] & 0xffffffffull] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) pose[u] = act[u] ? (size_t)bm_pose_of(T, row[u]) : 0;
+        double pr[U][7], lc[U][3], rc[U][3];
+        uint32_t lterm[U], rterm[U];
+        int32_t rslot[U], lslot[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const double *prow = T->poses + pose[u] * T->stride;
+#pragma unroll
+            for (int c = 0; c < 7; c++) pr[u][c] = act[u] ? prow[c] : 1.0;
+            lc[u][0] = T->m.lig.x[la[u]]; lc[u][1] = T->m.lig.y[la[u]]; lc[u][2] = T->m.lig.z[la[u]];
+            rc[u][0] = T->m.rec_x[ra[u]]; rc[u][1] = T->m.rec_y[ra[u]]; rc[u][2] = T->m.rec_z[ra[u]];
+            lterm[u] = T->m.lig.tindex[la[u]];
+            rterm[u] = T->m.rec_tindex[ra[u]];
+            rslot[u] = T->m.rec_slot[ra[u]];
+            lslot[u] = T->m.lig.slot[la[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!act[u]) continue;
+            if (T->exact_pairs) atomicAdd(T->exact_pairs + row[u], 1u);
+            // the ligand atom as the reference poses it (src/dfire.rs:282-302: pose_ligand_atom's operations), then exact_pair's
+            const Quat q{pr[u][3], pr[u][4], pr[u][5], pr[u][6]};
+            const Quat r = qmul(qmul(q, Quat{0.0, lc[u][0], lc[u][1], lc[u][2]}), qinverse(q));
+            const double px = r.x + pr[u][0], py = r.y + pr[u][1], pz = r.z + pr[u][2];
+            const double dx = 2.0 * rc[u][0] - 2.0 * px, dy = 2.0 * rc[u][1] - 2.0 * py, dz = 2.0 * rc[u][2] - 2.0 * pz;
+            const double D = dx * dx + dy * dy + dz * dz;   // = 4 d2 bit for bit (src/dfire.rs:331-333)
+            if (!(D <= kCutScaled)) continue;   // d2 <= 225 (src/dfire.rs:334)
+            uint32_t bin = 0;   // src/dfire.rs:336-337 as a count of the steps passed
+            for (int b = 1; b <= 20; b++) bin += D >= ex0.step4[b] ? 1u : 0u;
+            if (D <= ex0.iface_scaled) {   // d <= 3.9 (src/dfire.rs:339-342)
+                uint32_t *flags = T->flags + pose[u] * flag_words;
+                if (rslot[u] >= 0) atomicOr(&flags[rslot[u] >> 5], 1u << (rslot[u] & 31));
+                if (lslot[u] >= 0) atomicOr(&flags[T->m.rec_flag_words + (lslot[u] >> 5)], 1u << (lslot[u] & 31));
+            }
+            // a counting launch sums ones: the pair counts if it is within the cutoff
+            const long long fix = T->count_mode ? 1ll : __double2ll_rn(ex0.table[(lterm[u] + rterm[u] + tiled_bin_term(bin)) / 8u] * T->m.fix_scale);
+            if (fix != 0) atomicAdd(reinterpret_cast<unsigned long long *>(T->exact_fix + row[u]), (unsigned long long)fix);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the list is read before it is written again
+}
+
+__device__ __forceinline__ uint32_t bm_cell(float Rs, float Rz, float Ry, float Rx, float l2, float lz, float ly, float lx) {
+    // one half of the batch's packed chain: v_pk_add (Rs - l2), three v_pk_fma; v_cvt_u32_f32 (negative, NaN -> 0)
+    float D = Rs - l2;
+    D = __builtin_fmaf(Rz, lz, D);
+    D = __builtin_fmaf(Ry, ly, D);
+    D = __builtin_fmaf(Rx, lx, D);
+    uint32_t c;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(c) : "v"(D));
+    return c;
+}
+
+// (entry, block) items with several flagged pairs -> the list of pairs.  An item = entry of the pass | ligand subtile of the tile
+// << 32 | receptor subtile of the tile << 35: like a pair item it needs nothing of the job it came from, so the wave collects
+// 64 of them before it spends a call and 64 pair loops on them.
+__device__ __forceinline__ unsigned long long bm_block_item(size_t entry, int a, int b) {
+    return (unsigned long long)entry | (unsigned long long)a << 32 | (unsigned long long)b << 35;
+}
+__device__ __forceinline__ uint32_t bm_recheck(BmArgs *T, const unsigned char *lut, const unsigned long long *blocks, uint32_t n_blocks,
+                                            unsigned long long *queue, uint32_t n_pairs, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    constexpr float seed = (float)kBmCellZero + 0.5f;
+    const int n_rt = T->m.rec_n_tiles;
+    for (uint32_t base = 0; base < n_blocks; base += 64) {
+    if (n_pairs > (uint32_t)kBmQueuePairs - 4096u - (uint32_t)(8 * kBmPartEntries)) {   // room for 64 x 64 more, and still for a job's pushes
+        bm_exact_pairs(T, queue, n_pairs, lane);
+        n_pairs = 0;
+    }
+    const bool act = base + (uint32_t)lane < n_blocks;
+    const unsigned long long item = act ? __hip_atomic_load(blocks + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    const size_t entry = (size_t)(item & 0xffffffffull);
+    const int a = (int)((item >> 32) & 7u), b = (int)((item >> 35) & 7u);
+    const size_t tp = entry / T->cap;
+    const int lt = (int)(tp / (unsigned)n_rt), RT = (int)(tp % (unsigned)n_rt), ls = lt * 8 + a;
+    // the lane's pose and block, as the batch saw them
+    const float4 *ap = reinterpret_cast<const float4 *>(T->rt) + (size_t)(act ? T->ent_row[entry] : 0u) * 3;   // (an idle lane's entry 0 may never have been written)
+    const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+    const TiledBox box = T->m.rec_sub[(size_t)RT * 8 + b];
+    const float cbx = 0.5f * (box.lox + box.hix), cby = 0.5f * (box.loy + box.hiy), cbz = 0.5f * (box.loz + box.hiz);
+    const Affine A{a0.x, a0.y, a0.z, a0.w - cbx, a1.x, a1.y, a1.z, a1.w - cby, a2.x, a2.y, a2.z, a2.w - cbz};
+    float lx[8], ly[8], lz[8], l2[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float4 L = reinterpret_cast<const float4 *>(T->m.lig_local)[ls * 8 + i];
+        bm_apply(A, L.x, L.y, L.z, lx[i], ly[i], lz[i]);
+        l2[i] = __builtin_fmaf(lx[i], lx[i], __builtin_fmaf(ly[i], ly[i], lz[i] * lz[i]));
+    }
+    const float *rec = reinterpret_cast<const float *>(T->m.rec_pairs + (size_t)RT * 32 + b * 4);   // 4 records: x0 x1 y0 y1 z0 z1 . .
+#pragma unroll 1
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const float x = rec[q * 8 + h] - cbx, y = rec[q * 8 + 2 + h] - cby, z = rec[q * 8 + 4 + h] - cbz;
+            const float Rs = __builtin_fmaf(-x, x, __builtin_fmaf(-y, y, __builtin_fmaf(-z, z, seed)));
+            const float Rx = x * 2.f, Ry = y * 2.f, Rz = z * 2.f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t cell = bm_cell(Rs, Rz, Ry, Rx, l2[i], lz[i], ly[i], lx[i]);
+                const bool hit = act && lut[cell] == kBmFlagged;
+                const unsigned long long m = __ballot(hit);
+                if (hit) {
+                    const uint32_t at = n_pairs + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    queue[at] = bm_pair_item(entry, ls * 8 + i, RT * 64 + b * 8 + 2 * q + h);
+                }
+                n_pairs += (uint32_t)__popcll(m);
+            }
+        }
+    }
+    }
+    return n_pairs;
+}
+
+// DEBUG: per-wave phase timers (LIGHTDOCK_BM_DEBUG) -- the production instantiation carries none.
+template <bool DEBUG>
+__global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
-    __shared__ __attribute__((aligned(16))) BmShared S;
+    __shared__ __attribute__((aligned(16))) BmShared S;   // the kernel's only LDS object: at LDS address 0
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_rt = T->m.rec_n_tiles;
     {
-        const uint8_t *lut = COUNT ? T->m.lut_full : T->m.lut;
+        const uint8_t *lut = T->count_mode ? T->m.lut_full : T->m.lut;
         for (int i = tid; i < kBmLutBytes / 16; i += kBmWaves * 64) reinterpret_cast<uint4 *>(S.lut)[i] = reinterpret_cast<const uint4 *>(lut)[i];
     }
     BmWaveShared &WS = S.w[wave];
-    if (lane < 4) reinterpret_cast<uint32_t *>(WS.cube + kBmCubeRows * kBmRowBytes)[lane] = 0u;   // the zero slot behind the last row
     __syncthreads();
-    const unsigned char *cube = WS.cube;
     const uint32_t n_jobs = T->job_count[3], part_entries = T->job_count[2];
-    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long dbg_jobs = 0, dbg_batches = 0, dbg_t_batch = 0, dbg_t_drain = 0, dbg_t_scan = 0, dbg_drains = 0;
+    unsigned long long *queue = T->queue + ((size_t)blockIdx.x * kBmWaves + wave) * kBmQueueCap;   // the wave's flagged pairs
+    unsigned long long *queue_blocks = queue + kBmQueuePairs;                                        // (entry, block) items with several
+    uint32_t queued = 0, queued_blocks = 0;   // wave-uniform: flagged pairs listed; (entry, block) items listed
+    const unsigned char *table_rows = reinterpret_cast<const unsigned char *>(T->count_mode ? T->m.rows_ones : T->m.rows);
+    const unsigned long long dbg_t0 = DEBUG ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long dbg_jobs = 0, dbg_batches = 0, dbg_t_batch = 0, dbg_t_drain = 0, dbg_t_scan = 0, dbg_t_block = 0;
+    auto now = [] { return DEBUG ? __builtin_amdgcn_s_memrealtime() : 0ull; };
 
     for (;;) {
-        const unsigned long long dbg_tj = T->debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        const unsigned long long dbg_tj = now();
         uint32_t job = 0;
         if (lane == 0) job = atomicAdd(T->job_next, 1u);   // (drawing one job ahead was measured: the 2048 claimed jobs lengthen the tail)
         job = (uint32_t)__builtin_amdgcn_readfirstlane((int)job);
         if (job >= n_jobs) break;
         job = T->job_order[job];   // longest first (dfire_bm_order)
         const uint32_t jd = job / (uint32_t)kBmJobRows;
-        const int jrow = (int)(job % (uint32_t)kBmJobRows);   // partial-sum row of the entry: (job row of the tile, part of its blocks)
-        const int arow = jrow / kBmHalves, b_lo = (jrow % kBmHalves) * (8 / kBmHalves);
-        const int a = arow / kBmSplit, la0 = (arow % kBmSplit) * kBmLig;   // ligand subtile a, its atoms la0 .. la0 + kBmLig - 1
-        const uint32_t b_mask = ((1u << (8 / kBmHalves)) - 1u) << b_lo;      // the job's blocks (a, b_lo .. b_lo + 8 / kBmHalves - 1)
+        const int a = (int)(job % (uint32_t)kBmJobRows);   // ligand subtile a of the tile = partial-sum row of the entry
         const size_t tp = T->jobs[2 * jd];
         const uint32_t lo = T->jobs[2 * jd + 1];
         const uint32_t n = T->tp_count[tp];
@@ -646,8 +773,6 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
         const int n_chunks = (int)((hi - lo + 63) / 64);
         const int lt = (int)(tp / (unsigned)n_rt), RT = (int)(tp % (unsigned)n_rt);
         const int ls = lt * 8 + a;
-        const BmWaveCtx W{tp, ls, RT, lo};
-        const bool lig_tracked = T->m.lig_sub_tracked[ls] != 0;
 
         // What the job's blocks need that does not depend on the entry, for all 8 receptor subtiles of the tile at once (one
         // latency, together with the masks): lane = (receptor subtile b, atom j).
@@ -656,20 +781,24 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
 #pragma unroll
         for (int k = 0; k < 4; k++) recf[k] = reinterpret_cast<const float *>(T->m.rec_pairs + (size_t)RT * 32)[k * 64 + lane];
         const TiledBox my_box = T->m.rec_sub[(size_t)RT * 8 + (lane & 7)];           // lane b (mod 8): subtile b's box
-        const uint32_t my_tracked = T->m.rec_sub_tracked[RT * 8 + (lane & 7)];
         uint32_t any_bits = 0;
-        {   // the job's block masks: all loads in flight at once
+        {   // the job's block masks and rows of the pass: all loads in flight at once
             static_assert(kBmPartEntries == 1024, "16 chunks of 64 entries");
             unsigned long long m[16];
+            uint32_t r[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t e = lo + (uint32_t)k * 64 + lane;
                 m[k] = e < hi ? T->ent_mask[tp * T->cap + e] : 0ull;
+                r[k] = e < hi ? T->ent_row[tp * T->cap + e] : 0u;
             }
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const uint32_t bits = (uint32_t)(m[k] >> (8 * a)) & b_mask;
-                if (k < n_chunks) WS.row_bits[k * 64 + lane] = (unsigned char)bits;
+                const uint32_t bits = (uint32_t)(m[k] >> (8 * a)) & 0xffu;
+                if (k < n_chunks) {
+                    WS.row_bits[k * 64 + lane] = (unsigned char)bits;
+                    WS.rows[k * 64 + lane] = (unsigned short)r[k];
+                }
                 any_bits |= bits;
             }
         }
@@ -677,42 +806,37 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
         for (int off = 32; off > 0; off >>= 1) any_bits |= (uint32_t)__shfl_xor((int)any_bits, off, 64);
         any_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)any_bits);
         if (any_bits == 0) continue;
-        dbg_jobs++;
+        if (DEBUG) dbg_jobs++;
 
         // the ligand subtile's local coordinates (uniform)
         // (kept in LDS, read back per batch as broadcasts: 24 wave-uniform values in vector registers for the whole job are what
         // pushed the block set-up into scratch)
-        if (lane < kBmLig) WS.lig_local[lane] = reinterpret_cast<const float4 *>(T->m.lig_local)[ls * 8 + la0 + lane];
-        // table rows of a block -> LDS: kBmCubeRows * 11 pieces of 16 bytes, one LDS-DMA instruction per KiB
-        constexpr int kPieces = kBmCubeRows * 11, kDma = (kPieces + 63) / 64;
-        uint32_t src_lig[kDma];
-#pragma unroll
-        for (int t = 0; t < kDma; t++) {
-            const int piece = t * 64 + lane, row = piece / 11;
-            src_lig[t] = piece < kPieces ? T->m.lig_rowbase[ls * 8 + la0 + (row >> 3)] + (uint32_t)(piece % 11) * 16u : 0u;
-        }
-        const size_t row_base = (tp * kBmJobRows + (size_t)jrow) * T->cap + lo;
-        const size_t ent_base = tp * T->cap + lo;
-        uint32_t queued = 0;   // wave-uniform
-
-        if (T->debug) dbg_t_scan += __builtin_amdgcn_s_memrealtime() - dbg_tj;   // job set-up
+        if (lane < 8) WS.lig_local[lane] = reinterpret_cast<const float4 *>(T->m.lig_local)[ls * 8 + lane];
+        // table rows of a block -> LDS by LDS-DMA: an instruction copies 6 rows, lane = (row of the six, one of its 10 pieces of
+        // 16 bytes) -- the lane's two numbers are the same for every instruction, 60 lanes take part (piece p of an instruction
+        // lands at its LDS address + 16 p: six rows of 160 bytes, contiguous).  The lane keeps the row block of ligand atom
+        // lane % 8 (where its type's rows start in the table).
+        constexpr int kRowPieces = kBmRowBytes / 16, kDmaRows = 64 / kRowPieces, kDma = (kBmCubeRows + kDmaRows - 1) / kDmaRows;
+        static_assert(kRowPieces == 10 && kDmaRows == 6 && kDma == 11, "six rows per copy");
+        const uint32_t lig_rowbase = T->m.lig_rowbase[ls * 8 + (lane & 7)];
+        const size_t row_base = (tp * kBmJobRows + (size_t)a) * T->cap + lo;
+        const size_t row_base_entry = tp * T->cap + lo;
+        if (DEBUG) dbg_t_scan += now() - dbg_tj;   // job set-up
         for (int b = 0; b < 8; b++) {
             if (!((any_bits >> b) & 1u)) continue;
-            const unsigned long long dbg_tblk = T->debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
+            const unsigned long long dbg_tblk = now();
             {   // stage the block's rows; they land while the entries are scanned
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous block's reads are done
-                const unsigned char *rows = reinterpret_cast<const unsigned char *>(T->m.rows);
+                const int dma_row = lane / kRowPieces;                          // (constants of the lane)
+                const uint32_t dma_piece = (uint32_t)(lane % kRowPieces) * 16u;
 #pragma unroll
                 for (int t = 0; t < kDma; t++) {
-                    const int row = (t * 64 + lane) / 11;
-                    const uint32_t roff = (uint32_t)__shfl((int)roff_all, b * 8 + (row & 7), 64);
-                    if (t * 64 + 63 < kPieces || t * 64 + lane < kPieces)   // (the last KiB may be partial)
-                        __builtin_amdgcn_global_load_lds((const global_u32 *)(rows + (src_lig[t] + roff)), (lds_u32 *)(WS.cube + t * 1024), 16, 0, 0);
+                    const int row = t * kDmaRows + dma_row;   // (i, j) = (row / 8, row % 8)
+                    const uint32_t src = (uint32_t)__shfl((int)lig_rowbase, (row >> 3) & 7, 64) + (uint32_t)__shfl((int)roff_all, b * 8 + (row & 7), 64) + dma_piece;
+                    if (lane < kDmaRows * kRowPieces && row < kBmCubeRows)
+                        __builtin_amdgcn_global_load_lds((const global_u32 *)(table_rows + src), (lds_u32 *)(S.cube[wave] + t * (kDmaRows * kBmRowBytes)), 16, 0, 0);
                 }
             }
-            // A block with an atom that has an interface-flag slot also queues its pairs closer than 2.5 A (bins 0 and 1,
-            // whose slots are the last two of a row) for the exact path, which sets the flags (src/dfire.rs:339-342).
-            const uint32_t flag_from = lig_tracked || __builtin_amdgcn_readlane((int)my_tracked, b) != 0 ? kBmNearCode : kBmFlagged;
             constexpr float seed = (float)kBmCellZero + 0.5f;
             // ---- the job's entries that hold block (a, b), in entry order (all 16 chunks' bytes in flight, then the ballots)
             uint32_t n_items = 0;
@@ -727,7 +851,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                     const unsigned long long m = __ballot(act);
                     if (act) {
                         const uint32_t at = n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        const bool first = (bits & ((1u << b) - 1u)) == 0u;   // the entry's first block of this job (bits hold the job's blocks only): nothing to add to yet
+                        const bool first = (bits & ((1u << b) - 1u)) == 0u;   // the entry's first block of this job: nothing to add to yet
                         WS.items[at] = (unsigned short)((uint32_t)(k * 64 + lane) | (first ? 0x8000u : 0u));
                     }
                     n_items += (uint32_t)__popcll(m);
@@ -739,7 +863,7 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
             // four packed operations per step instead of six (the differences need not be formed), all operands small
             // enough (below 2^17 for every pair within reach of the cutoff) that the roundings stay inside eps.  The LUT
             // is indexed from the far end: a pair beyond its last cell has E < 0, which v_cvt_u32_f32 turns into cell' 0
-            // ("miss") like a NaN -- no clamp.
+            // ("miss") like a NaN -- no clamp.  (bm_drain repeats this arithmetic: keep the two in step.)
             auto lane_f32 = [](float v, int from) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), from)); };
             const float cbx = 0.5f * (lane_f32(my_box.lox, b) + lane_f32(my_box.hix, b));
             const float cby = 0.5f * (lane_f32(my_box.loy, b) + lane_f32(my_box.hiy, b));
@@ -757,11 +881,11 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                 Ry[q] = y * v2f{2.f, 2.f};
                 Rz[q] = z * v2f{2.f, 2.f};
             }
-            // what a lane of a batch needs from memory, loaded one batch ahead
+            // what a lane of a batch needs from memory, loaded one batch ahead: the pose's affine map out of the [row][12] table
+            // (L2: the pass's table is 48 bytes a pose) and the entry's partial sum so far
             struct BatchLoads {
                 float4 a0, a1, a2;   // the entry's affine map
-                double prev;         // the entry's partial of this row so far
-                uint32_t prev_cnt;
+                long long prev;      // the entry's partial of this row so far
                 uint32_t item;
             };
             auto issue_loads = [&](uint32_t first_item) {
@@ -769,154 +893,104 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
                 const uint32_t at = first_item + (uint32_t)lane;
                 L.item = WS.items[at < n_items ? at : first_item];
                 const uint32_t el = L.item & 0x7fffu;
-                const float4 *ap = reinterpret_cast<const float4 *>(T->ent_rt) + (ent_base + el) * 3;
+                const float4 *ap = reinterpret_cast<const float4 *>(T->rt) + (size_t)WS.rows[el] * 3;
                 L.a0 = ap[0];
                 L.a1 = ap[1];
                 L.a2 = ap[2];
-                L.prev = 0.0;
-                L.prev_cnt = 0;
-                if (!(L.item & 0x8000u)) {
-                    L.prev = T->ent_partial[row_base + el];
-                    if (COUNT) L.prev_cnt = T->ent_count[row_base + el];
-                }
+                L.prev = 0;
+                if (!(L.item & 0x8000u)) L.prev = T->ent_partial[row_base + el];
                 return L;
             };
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the item list as every lane wrote it
             BatchLoads next = issue_loads(0);
-            if (T->debug) dbg_drains += __builtin_amdgcn_s_memrealtime() - dbg_tblk;   // block set-up
-            for (uint32_t done = 0; done < n_items; done += 64) {
-                const BatchLoads cur = next;
-                dbg_batches++;
-                const unsigned long long dbg_tb = T->debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this batch's loads (and, the first time, the block's rows) are in
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (done + 64 < n_items) next = issue_loads(done + 64);
+            if (DEBUG) dbg_t_block += now() - dbg_tblk;   // block set-up
+
+            // ---- one batch: lane = entry.  WAVE = this wave's number in the workgroup, a constant of the code.
+            auto run_batch = [&](auto wave_constant, const BatchLoads &cur, uint32_t done) {
+                constexpr int WAVE = decltype(wave_constant)::value;
+                constexpr uint32_t kCube = (uint32_t)(offsetof(BmShared, cube) + (size_t)WAVE * kBmCubeBytes);   // a constant LDS address
                 const int count = n_items - done >= 64u ? 64 : (int)(n_items - done);
-                const bool valid = lane < count;
+                const bool valid = lane < count;   // (the lanes beyond `count` repeat the first item)
                 const uint32_t el = cur.item & 0x7fffu;
                 const Affine A{cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w - cbx, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w - cby, cur.a2.x, cur.a2.y, cur.a2.z, cur.a2.w - cbz};
-                v2f lxy[kBmLig], lz2[kBmLig];   // l - c as {x, y} and {z, |l - c|^2}: the packed operations broadcast either half (op_sel)
+                v2f lxy[8], lz2[8];   // l - c as {x, y} and {z, |l - c|^2}: the packed operations broadcast either half (op_sel)
 #pragma unroll
-                for (int i = 0; i < kBmLig; i++) {
+                for (int i = 0; i < 8; i++) {
                     float lx, ly, lz;
                     const float4 L = WS.lig_local[i];
                     bm_apply(A, L.x, L.y, L.z, lx, ly, lz);
                     lxy[i] = v2f{lx, ly};
                     lz2[i] = v2f{lz, __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz))};
                 }
-                double acc = 0.0;
-                uint32_t cnt = 0;
-                // The batch's steps (ligand atom i x the receptor pair record q, 2 atom pairs each) in groups of 8: all cells, all
-                // codes, all table values of a group in flight, then the adds in order and one test for flagged cells.
-                // Step t of the batch: q = t / kBmLig, i = t % kBmLig.
-                constexpr int kGroups = kBmLig / 2;
-                auto codes_of_group = [&](int g, uint32_t (&w)[16]) {
-#pragma unroll
-                    for (int s8 = 0; s8 < 8; s8 += 2) {
-                        static_assert(kBmLig == 8, "the two steps of a pair share the receptor record");
-                        const int t = g * 8 + s8, q = t / kBmLig, i = t % kBmLig;
-                        // Two steps (ligand atoms i, i + 1 against the receptor record q) as ONE block of instructions:
-                        //   D = Rs - l2; D = fma(Rz, lz, D); D = fma(Ry, ly, D); D = fma(Rx, lx, D), both halves; cell = (u32)D
-                        // Written out because the compiler duplicates the broadcast operands into register pairs (32 moves a
-                        // group) instead of using op_sel; as one block because it guards every separate asm statement with an
-                        // s_nop (128 per batch); the two dependent chains interleaved.
-                        v2f D0, D1;
-                        uint32_t c0, c1, c2, c3;
-                        asm("v_pk_add_f32 %[d0], %[rs], %[za] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                            "v_pk_add_f32 %[d1], %[rs], %[zb] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                            "v_pk_fma_f32 %[d0], %[rz], %[za], %[d0] op_sel_hi:[1,0,1]\n\t"
-                            "v_pk_fma_f32 %[d1], %[rz], %[zb], %[d1] op_sel_hi:[1,0,1]\n\t"
-                            "v_pk_fma_f32 %[d0], %[ry], %[xa], %[d0] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                            "v_pk_fma_f32 %[d1], %[ry], %[xb], %[d1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                            "v_pk_fma_f32 %[d0], %[rx], %[xa], %[d0] op_sel_hi:[1,0,1]\n\t"
-                            "v_pk_fma_f32 %[d1], %[rx], %[xb], %[d1] op_sel_hi:[1,0,1]"
-                            : [d0] "=&v"(D0), [d1] "=&v"(D1)
-                            : [rs] "v"(Rs[q]), [rz] "v"(Rz[q]), [ry] "v"(Ry[q]), [rx] "v"(Rx[q]), [za] "v"(lz2[i]), [xa] "v"(lxy[i]),
-                              [zb] "v"(lz2[i + 1]), [xb] "v"(lxy[i + 1]));
-                        // (v_cvt_u32_f32 saturates: negative and NaN -> 0)
-                        asm("v_cvt_u32_f32 %0, %4\n\tv_cvt_u32_f32 %1, %5\n\tv_cvt_u32_f32 %2, %6\n\tv_cvt_u32_f32 %3, %7"
-                            : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3) : "v"(D0.x), "v"(D0.y), "v"(D1.x), "v"(D1.y));
-                        w[2 * s8] = S.lut[c0];
-                        w[2 * s8 + 1] = S.lut[c1];
-                        w[2 * s8 + 2] = S.lut[c2];
-                        w[2 * s8 + 3] = S.lut[c3];
-                    }
-                };
-                // (computing the codes of group g + 1 while the table values of group g are on their way was tried: the second
-                // wave of the SIMD already fills those waits, and the 16 extra live registers spill the block set-up)
-#pragma unroll
-                for (int g = 0; g < kGroups; g++) {
-                    uint32_t w[16];
-                    codes_of_group(g, w);
-#pragma unroll
-                    for (int k = 0; k < 16; k++) asm("" : "+v"(w[k]));   // 32-bit values from here on (no 16-bit detours on the way to the address)
-                    double tv[16];
-#pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        const int t = g * 8 + (k >> 1), q = t / kBmLig, i = t % kBmLig;
-                        tv[k] = *reinterpret_cast<const double *>(cube + (i * 8 + 2 * q + (k & 1)) * kBmRowBytes + w[k]);
-                    }
-                    uint32_t wm = 0;
-#pragma unroll
-                    for (int s8 = 0; s8 < 8; s8++) {
-                        acc += tv[2 * s8];
-                        acc += tv[2 * s8 + 1];
-                        if (COUNT && WS.lig_local[(g * 8 + s8) % kBmLig].w != 0.f)
-                            cnt += (w[2 * s8] != 0u && w[2 * s8] < kBmFlagged ? 1u : 0u) + (w[2 * s8 + 1] != 0u && w[2 * s8 + 1] < kBmFlagged ? 1u : 0u);
-                        const uint32_t m2 = w[2 * s8] > w[2 * s8 + 1] ? w[2 * s8] : w[2 * s8 + 1];
-                        wm = wm > m2 ? wm : m2;
-                    }
-                    asm volatile("" : "+v"(acc));   // the group's adds end here (the scheduler would park table values in registers)
-                    if (__builtin_expect(__ballot(wm >= flag_from) != 0ull, 0)) {
-                        // Pairs in flagged cells read 0.0 above; queue them for the exact path.  Most groups of a 1k4c
-                        // batch come here for one or two of their 1024 pairs, so the way in is vector-only: every lane
-                        // turns its 16 codes into a bit mask (no scalar compare-and-branch per code: 16 of those cost four
-                        // times the group's arithmetic), then the few lanes with a bit set push one pair per round.
-                        // (two operations per code and no compare: the sign of code - threshold shifted in by v_alignbit_b32)
-                        uint32_t fm = 0, fm_only = 0;   // bit k: pair k of the group goes to the exact path / for its flags only
-#pragma unroll
-                        for (int k = 15; k >= 0; k--) fm = __builtin_amdgcn_alignbit(fm, w[k] - flag_from, 31);   // fm << 1 | (code below the threshold)
-                        fm = ~fm & 0xffffu;
-                        if (flag_from != kBmFlagged) {   // a block with tracked atoms (wave-uniform, rare)
-#pragma unroll
-                            for (int k = 15; k >= 0; k--) fm_only = __builtin_amdgcn_alignbit(fm_only, w[k] - kBmFlagged, 31);
-                        }
-                        if (!valid) fm = 0;
-                        unsigned long long live = __ballot(fm != 0u);
-                        while (live != 0ull) {
-                            if (queued > (uint32_t)kBmQueue - 64u) {   // room for 64 more, always: a pose's sum never depends on its batch
-                                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                                bm_drain<COUNT>(T, W, WS.queue, queued, lane);
-                                queued = 0;
-                            }
-                            const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-                            if (fm != 0u) {
-                                const uint32_t k = (uint32_t)__builtin_ctz(fm);
-                                const uint32_t t = (uint32_t)g * 8u + (k >> 1), q = t / (uint32_t)kBmLig, i = t % (uint32_t)kBmLig;   // the step, its pair k & 1
-                                WS.queue[at] = el | (((uint32_t)la0 + i) * 8u + 2u * q + (k & 1u)) << 10 | (uint32_t)b << 16 |
-                                               ((fm_only >> k) & 1u ? kBmFlagsOnly : 0u);
-                                fm &= fm - 1u;
-                            }
-                            queued += (uint32_t)__popcll(live);
-                            live = __ballot(fm != 0u);
-                        }
-                    }
+                // The batch's 64 pairs: dfire_bm_batch.inc (generated, tools/gen_bm_batch_asm.py).  Fixed-point sum: table
+                // values are integers (2^-k units, exact adds in any order); a flagged cell's slot holds the row's marker.
+                unsigned long long acc = 0ull;
+                LD_BM_BATCH_ASM(acc, Rs, Rz, Ry, Rx, lz2, lxy, kCube);
+                const long long sum = (long long)acc;
+                const long long mark = (sum + (1ll << (kBmMarkerShift - 1))) >> kBmMarkerShift;   // |true sum| < 2^49 (the scale is chosen for that)
+                const long long part = sum - (mark << kBmMarkerShift);
+                const bool one = valid && mark >= 64 && mark < 128, several = valid && mark >= 128;
+                const unsigned long long m1 = __ballot(one), m2 = __ballot(several);
+                if (one) {   // the lane's one pair in a flagged cell (0.1 % of all pairs): the exact path
+                    const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+                    const int pair = (int)mark - 64;
+                    queue[at] = bm_pair_item(row_base_entry + el, ls * 8 + (pair >> 3), RT * 64 + b * 8 + (pair & 7));
                 }
-                if (valid) {
-                    T->ent_partial[row_base + el] = cur.prev + acc;
-                    if (COUNT) T->ent_count[row_base + el] = cur.prev_cnt + cnt;
+                queued += (uint32_t)__popcll(m1);
+                if (__builtin_expect(m2 != 0ull, 0)) {
+                    if (several) {
+                        const uint32_t at = queued_blocks + __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+                        queue_blocks[at] = bm_block_item(row_base_entry + el, a, b);
+                    }
+                    queued_blocks += (uint32_t)__popcll(m2);
                 }
-                if (T->debug) dbg_t_batch += __builtin_amdgcn_s_memrealtime() - dbg_tb;
+                if (valid) T->ent_partial[row_base + el] = cur.prev + part;
+            };
+            for (uint32_t done = 0; done < n_items; done += 64) {
+                if (DEBUG) dbg_batches++;
+                const unsigned long long dbg_tb = now();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this batch's loads (and, the first time, the block's rows) are in
+                const BatchLoads cur = next;
+                // the rows' markers, over what the copy left in their slots (they name the PAIR: not part of the table)
+                if (done == 0) *reinterpret_cast<long long *>(S.cube[wave] + lane * kBmRowBytes + kBmFlagged) = (long long)(64 + lane) << kBmMarkerShift;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // (in the code all waves share, and unconditional -- the block's last batch asks for its first items again -- so that the
+                // loads land in the registers the next trip reads them from: behind a branch the compiler moved them there
+                // right away, i.e. waited for them)
+                next = issue_loads(done + 64 < n_items ? done + 64 : 0u);
+                switch (wave) {
+                    case 0: run_batch(std::integral_constant<int, 0>{}, cur, done); break;
+                    case 1: run_batch(std::integral_constant<int, 1>{}, cur, done); break;
+                    case 2: run_batch(std::integral_constant<int, 2>{}, cur, done); break;
+                    default: run_batch(std::integral_constant<int, 3>{}, cur, done); break;
+                }
+                if (DEBUG) dbg_t_batch += now() - dbg_tb;
             }
         }
-        if (queued) {
-            const unsigned long long td = T->debug ? __builtin_amdgcn_s_memrealtime() : 0ull;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            bm_drain<COUNT>(T, W, WS.queue, queued, lane);
-            if (T->debug) dbg_t_drain += __builtin_amdgcn_s_memrealtime() - td;
+        // The exact path, at the job's end only: no call inside the block and batch loops (the compiler keeps what lives across
+        // a call site in scratch for the whole job), and the lists have room for everything one job can push.
+        if (queued_blocks >= 64u) {
+            const unsigned long long td = now();
+            queued = bm_recheck(T, S.lut, queue_blocks, queued_blocks, queue, queued, lane);
+            queued_blocks = 0;
+            if (DEBUG) dbg_t_drain += now() - td;
+        }
+        // (a few hundred pairs at a time: often enough that the other waves' batches hide its memory latencies -- everything at
+        // the wave's end was a 230 us tail of the whole launch -- and seldom enough that the calls do not count)
+        if (queued >= (uint32_t)kBmDrainAt) {
+            const unsigned long long td = now();
+            bm_exact_pairs(T, queue, queued, lane);
+            queued = 0;
+            if (DEBUG) dbg_t_drain += now() - td;
         }
     }
-    if (T->debug != nullptr && lane == 0) {
+    {
+        const unsigned long long td = now();
+        if (queued_blocks) queued = bm_recheck(T, S.lut, queue_blocks, queued_blocks, queue, queued, lane);
+        if (queued) bm_exact_pairs(T, queue, queued, lane);
+        if (DEBUG) dbg_t_drain += now() - td;
+    }
+    if (DEBUG && T->debug != nullptr && lane == 0) {
         unsigned long long *d = T->debug + ((size_t)blockIdx.x * kBmWaves + wave) * 8;
         d[0] = dbg_t0;
         d[1] = __builtin_amdgcn_s_memrealtime();
@@ -924,25 +998,27 @@ __global__ __launch_bounds__(kBmWaves * 64, (kBmWaves + 3) / 4) void dfire_bm_pa
         d[3] = dbg_batches;
         d[4] = dbg_t_batch;
         d[5] = dbg_t_drain;
-        d[6] = dbg_drains;
+        d[6] = dbg_t_block;
         d[7] = dbg_t_scan;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// dfire_bm_gather: wave = pose; lanes over the ligand tiles, fixed order, then a fixed tree
+// dfire_bm_gather: thread = (row, ligand tile[, share of its entries]); fixed order, then a fixed tree.  The partial sums
+// are integers (fixed point); a pose's total can exceed 63 bits for an extreme table, so they are added as f64, exact up to
+// 2^53 units each, in the one order that depends on the molecules only.  A counting launch (count_mode) sums ones.
 // ---------------------------------------------------------------------------------------------
-template <bool COUNT>
 __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
     __shared__ double s_sum[512];
-    __shared__ uint32_t s_cnt[512], s_tested[512];
+    __shared__ uint32_t s_tested[512];
     const int tid = threadIdx.x;
     const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
-    // thread = (pose, ligand tile); a workgroup holds 512 / span poses, span = the power of two that covers the ligand's
+    const bool counting = T->count_mode != 0;
+    // thread = (row, ligand tile); a workgroup holds 512 / span rows, span = the power of two that covers the ligand's
     // tiles.  The kernel is bound by the latency of three dependent loads per entry: many poses in flight per CU, and
     // per thread the partial sums of four entries x all their rows requested together.
-    // A small ligand leaves threads over: `chunks` of them share a (pose, ligand tile), each taking every chunks-th group of
+    // A small ligand leaves threads over: `chunks` of them share a (row, ligand tile), each taking every chunks-th group of
     // four entries (both numbers depend on the molecules only: a pose's sum is the same tree in every launch).
     const int span_lt = bm_gather_span(n_lt), chunks = bm_gather_chunks(n_lt, n_rt), span = span_lt * chunks;
     const int per_wg = 512 / span, sub = tid / span, r0 = tid % span;
@@ -951,64 +1027,53 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
     for (size_t first_row = (size_t)blockIdx.x * per_wg; first_row < n_rows; first_row += (size_t)gridDim.x * per_wg) {
     const size_t listed = first_row + sub;
     const long long pp = listed < n_rows ? bm_pose_of(T, listed) : -1;
-    const size_t pose = pp < 0 ? 0 : (size_t)pp;
+    const size_t pose = pp < 0 ? 0 : (size_t)pp, row = pp < 0 ? 0 : listed;
     double s = 0.0;
-    uint32_t cnt = 0, tested = 0;
+    uint32_t tested = 0;
     for (int lt = lt0; pp >= 0 && lt < n_lt; lt += span_lt) {   // the tile's entries in the order the culling listed them, their rows in order
-        const size_t slot = pose * (size_t)n_lt + lt;
-        if (COUNT && chunk == 0) tested += T->tile_tested[slot];
+        const size_t slot = row * (size_t)n_lt + lt;
+        if (counting && T->tile_tested && chunk == 0) tested += T->tile_tested[slot];
         const uint32_t n_vis = T->vis_count[slot];
         for (uint32_t v0 = 4u * (uint32_t)chunk; v0 < n_vis; v0 += 4u * (uint32_t)chunks) {
             unsigned long long ent[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) ent[k] = v0 + k < n_vis ? T->vis_entry[slot * (size_t)n_rt + v0 + k] : 0ull;
-            double part[4][kBmJobRows];
-            uint32_t pc[4][kBmJobRows];
+            long long part[4][kBmJobRows];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const size_t tp = (size_t)lt * n_rt + (size_t)(ent[k] >> 48);
                 const size_t at = tp * kBmJobRows * T->cap + (size_t)(ent[k] & 0xffffffffull);
 #pragma unroll
                 for (int jrow = 0; jrow < kBmJobRows; jrow++) {
-                    const int sub_half = jrow / (kBmSplit * kBmHalves) * kBmHalves + jrow % kBmHalves;   // (ligand subtile, part of its blocks)
-                    const bool on = (ent[k] >> (32 + sub_half)) & 1ull;
-                    part[k][jrow] = on ? T->ent_partial[at + (size_t)jrow * T->cap] : 0.0;
-                    pc[k][jrow] = COUNT && on ? T->ent_count[at + (size_t)jrow * T->cap] : 0u;
+                    const bool on = (ent[k] >> (32 + jrow)) & 1ull;   // the entry holds a block of ligand subtile jrow
+                    part[k][jrow] = on ? T->ent_partial[at + (size_t)jrow * T->cap] : 0ll;
                 }
             }
 #pragma unroll
             for (int k = 0; k < 4; k++)
 #pragma unroll
-                for (int jrow = 0; jrow < kBmJobRows; jrow++) {
-                    s += part[k][jrow];   // (a row without a block of the entry adds 0.0: no bit of the sum changes)
-                    cnt += pc[k][jrow];
-                }
+                for (int jrow = 0; jrow < kBmJobRows; jrow++) s += (double)part[k][jrow];
         }
     }
     s_sum[tid] = s;
-    if (COUNT) {
-        s_cnt[tid] = cnt;
-        s_tested[tid] = tested;
-    }
+    if (counting) s_tested[tid] = tested;
     __syncthreads();
     for (int half = span >> 1; half > 0; half >>= 1) {   // fixed tree, per pose
         if (r0 < half) {
             s_sum[tid] += s_sum[tid + half];
-            if (COUNT) {
-                s_cnt[tid] += s_cnt[tid + half];
-                s_tested[tid] += s_tested[tid + half];
-            }
+            if (counting) s_tested[tid] += s_tested[tid + half];
         }
         __syncthreads();
     }
     if (r0 == 0 && pp >= 0) {
-        const double total = s_sum[tid] + (double)T->exact_fix[pose] * (1.0 / kBmFixScale);
-        T->partial[2 * pose] = total;
-        T->partial[2 * pose + 1] = 0.0;
-        if (COUNT) {
-            T->count_partial[pose] = s_cnt[tid] + T->exact_count[pose];
+        const double units = s_sum[tid] + (double)T->exact_fix[row];
+        if (counting) {   // (pair counts stay far below 2^53: exact)
+            T->count_partial[pose] = (uint32_t)units;
             if (T->tested_partial) T->tested_partial[pose] = s_tested[tid];
-            if (T->exact_partial) T->exact_partial[pose] = T->exact_pairs[pose];
+            if (T->exact_partial) T->exact_partial[pose] = T->exact_pairs[row];
+        } else {
+            T->partial[2 * pose] = units * (1.0 / T->m.fix_scale);
+            T->partial[2 * pose + 1] = 0.0;
         }
     }
     __syncthreads();   // s_sum is reused by the next rows
@@ -1027,19 +1092,19 @@ hipError_t launch_bm_pose(const BmLaunch &t, hipStream_t stream) {
 
 hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    if (t.m.rec_n_tiles > 255) return hipErrorInvalidValue;
+    if (t.m.rec_n_tiles > 65535 || t.n_poses > kBmMaxPassPoses) return hipErrorInvalidValue;
     const size_t lds = (size_t)t.m.rec_n_tiles * 9 * sizeof(TiledBox) + (size_t)kBmCullWaves * bm_cull_wave_lds(t.m.rec_n_tiles);
     // persistent workgroups (each fills its LDS with the receptor's boxes once): as many as fit the chip at this LDS size
     const size_t per_cu = std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512)));
     const size_t cus = t.pairs_groups > 0 ? (size_t)t.pairs_groups : 256;
     const size_t blocks = std::min<size_t>(((t.n_poses + kBmCullPoses - 1) / kBmCullPoses * (size_t)t.m.lig.n_tiles + kBmCullWaves - 1) / kBmCullWaves, cus * per_cu);
     if (lds > 64 * 1024) {   // (a receptor of more than ~100 tiles)
-        const hipError_t e = t.ent_count != nullptr
+        const hipError_t e = t.tile_tested != nullptr
             ? hipFuncSetAttribute(reinterpret_cast<const void *>(&dfire_bm_cull<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
             : hipFuncSetAttribute(reinterpret_cast<const void *>(&dfire_bm_cull<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_cull<true>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
+    if (t.tile_tested != nullptr) hipLaunchKernelGGL((dfire_bm_cull<true>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
     else hipLaunchKernelGGL((dfire_bm_cull<false>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
     return hipGetLastError();
 }
@@ -1049,8 +1114,11 @@ hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
     hipLaunchKernelGGL(dfire_bm_plan, dim3(1), dim3(1024), 0, stream, t);
     hipLaunchKernelGGL(dfire_bm_census, dim3(128), dim3(kBmOrderWaves * 64), 0, stream, t);
     hipLaunchKernelGGL(dfire_bm_order, dim3(1), dim3(kBmOrderWaves * 64), 0, stream, t);
-    const unsigned groups = t.pairs_groups > 0 ? (unsigned)t.pairs_groups : 256u;   // persistent: one workgroup per CU
-    if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_pairs<true>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
+    unsigned groups = (t.pairs_groups > 0 ? (unsigned)t.pairs_groups : 256u) * kBmGroupsPerCu;   // persistent: what the chip holds
+    if (const char *e = std::getenv("LIGHTDOCK_BM_HALF_OCCUPANCY")) {   // diagnostics: one workgroup per CU (one wave per SIMD)
+        if (std::atoi(e) == 1) groups /= kBmGroupsPerCu;
+    }
+    if (t.debug != nullptr) hipLaunchKernelGGL((dfire_bm_pairs<true>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
     else hipLaunchKernelGGL((dfire_bm_pairs<false>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
     return hipGetLastError();
 }
@@ -1060,8 +1128,7 @@ hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t stream) {
     const int span = bm_gather_span(t.m.lig.n_tiles) * bm_gather_chunks(t.m.lig.n_tiles, t.m.rec_n_tiles);
     const size_t per_wg = 512 / span;
     const unsigned blocks = (unsigned)std::min<size_t>((t.n_poses + per_wg - 1) / per_wg, 16384);
-    if (t.ent_count != nullptr) hipLaunchKernelGGL((dfire_bm_gather<true>), dim3(blocks), dim3(512), 0, stream, t);
-    else hipLaunchKernelGGL((dfire_bm_gather<false>), dim3(blocks), dim3(512), 0, stream, t);
+    hipLaunchKernelGGL(dfire_bm_gather, dim3(blocks), dim3(512), 0, stream, t);
     return hipGetLastError();
 }
 

@@ -3,34 +3,35 @@
 // Same sum as src/dfire.rs:325-345, same 64x64 / 8x8 box culling and the same f32-filter-with-exact-f64-path
 // numerics as dfire_packed.hpp, but the pair work is ordered by atom-pair BLOCK instead of by pose:
 //
-//   dfire_bm_pose    one thread per pose: the pose's rotation + translation as an f32 affine map into the record frame
+//   dfire_bm_pose    one thread per row of the pass: the pose's rotation + translation as an f32 affine map into the record
+//                    frame, [row][12], 48 bytes that stay in L2 for the whole pass
 //   dfire_bm_cull    persistent waves, one (ligand tile, 8 poses) item at a time: a bounding-sphere test of the tile against the
 //                    receptor's tile boxes (in LDS), then the ligand atoms posed in f32, boxes, 64x64 and 8x8 box tests; every
-//                    surviving (ligand tile, receptor tile) pair of a pose becomes one ENTRY {pose, 64-bit block mask, the
-//                    pose's affine map} appended to that tile pair's list (one global atomic per tile pair per wave)
+//                    surviving (ligand tile, receptor tile) pair of a pose becomes one ENTRY {row of the pass, 64-bit block mask}
+//                    appended to that tile pair's list (one global atomic per tile pair per wave)
 //   dfire_bm_plan    one workgroup: every tile pair's entries cut into parts of P entries
 //   dfire_bm_census  one wave per (tile pair, part): per ligand-subtile row the block bits of its entries -> the estimated
 //                    length of the JOB (tile pair, part, row)
 //   dfire_bm_order   one workgroup: the jobs that have any work, longest first (counting sort into classes)
-//   dfire_bm_pairs   persistent workgroups of 8 independent waves (one per CU); a wave draws a job and, for each of its 8
+//   dfire_bm_pairs   persistent workgroups of 4 independent waves (two per CU); a wave draws a job and, for each of its 8
 //                    blocks (a, b): the 64 table rows T[type_i][type_j][.] of the block are staged in the wave's slice of LDS
 //                    ONCE (dense L2 -> LDS copies by LDS-DMA), the entries whose mask holds the block are compacted into
 //                    batches of 64, and a batch runs lane = pose: the lane poses the 8 ligand atoms of subtile a (uniform
-//                    local coordinates, its pose's affine map) and walks the 64 atom pairs of the block, whose receptor
-//                    atoms and table rows are wave-uniform: E = cell-zero + 1/2 - 64 d2 in packed f32 (coordinates relative
-//                    to the receptor subtile's box centre), cell = (u32)E, code = lut[cell] (u8, LDS), value = row[code]
-//                    (f64, LDS), f64 add.  No gather ever leaves the CU: the L2 -> L1 line fills that bound the pose-major
-//                    kernel (0.5 lines of 128 B per in-cutoff pair) are gone.
-//   dfire_bm_gather  thread = (pose, ligand tile[, share of its entries]): the pose's partial sums in a fixed order -> the
+//                    local coordinates, its pose's affine map from the L2-resident [row][12] table) and walks the 64 atom
+//                    pairs of the block, whose receptor atoms and table rows are wave-uniform: E = cell-zero + 1/2 - 64 d2 in
+//                    packed f32 (coordinates relative to the receptor subtile's box centre), cell = (u32)E, code = lut[cell]
+//                    (u8, LDS), x = code - 8 with the borrow = "flagged cell" collected in a scalar mask, value = row[x]
+//                    (f64, LDS; the row's address is an instruction constant), f64 add.  No gather ever leaves the CU.
+//   dfire_bm_gather  thread = (row, ligand tile[, share of its entries]): the pose's partial sums in a fixed order -> the
 //                    [pose][1][2] partials that pose_energy_finish folds (restraint / membrane tail, src/dfire.rs:347-361)
 //
 // Numerics: records are u = fl32(8 (x - c)); the ligand is posed by an f32 affine map whose error
-// is part of `eps`; a LUT cell (1/16 of a unit of 4 d2) whose interval, widened by eps, holds a bin step, the interface
-// distance or the cutoff is FLAGGED: its pairs read 0.0 and are recomputed in f64 (exact_pair, dfire_device.hpp) from
-// the f64 coordinates with the reference's quaternion posing.  Bins, cutoff decisions and interface flags are therefore
-// the reference's, bit for bit; the energies differ from the other kernels by summation order only, and -- the one
-// liberty this path takes -- the exact path's values reach the pose's sum through a 64-bit fixed-point accumulator
-// (2^-40 units) so that their order cannot matter.
+// is part of `eps`; a LUT cell (1/16 of a unit of 4 d2) whose interval, widened by eps, holds a bin step, the cutoff or
+// distances below 2.5 A (bins 0 and 1, where the interface distance lies) is FLAGGED: its pairs read 0.0 and are
+// recomputed in f64 (exact_pair, dfire_device.hpp) from the f64 coordinates with the reference's quaternion posing.
+// Bins, cutoff decisions and interface flags are therefore the reference's, bit for bit; the energies differ from the
+// other kernels by summation order only, and -- the one liberty this path takes -- the exact path's values reach the
+// pose's sum through a 64-bit fixed-point accumulator (2^-40 units) so that their order cannot matter.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -48,31 +49,38 @@ constexpr int kBmCutCell = 900 * kBmCells;   // the cutoff 4 d2 = 900
 constexpr int kBmLutBytes = 14592;           // cells 0 .. 14591: everything beyond kBmCutCell + eps reads "miss"
 constexpr float kBmCellMax = 14591.0f;
 constexpr int kBmCellZero = 14583;            // the cell of 64 d2 = 0: E = kBmCellZero + 1/2 - 64 d2 stays inside the LUT for any error below 8 cells
-constexpr int kBmRowSlots = 22;              // slot 0 = 0.0 (miss), slots 1..19 = bins 2..20 (20 = the read past the row at r = 15.0), slots 20, 21 = bins 0, 1
+// A table row T[type_i][type_j][.] as the pair kernel reads it: 20 slots of 64-bit FIXED POINT (value * fix_scale, rounded
+// once on the host: integer adds are exact in any order, so a pose's sum does not depend on how the launch was cut up):
+// slots 0..17 = bins 2..19, slot 18 = 0 ("miss": beyond the cutoff, or a bin that is zero for the whole complex), slot 19 = the
+// MARKER a flagged cell reads (the cell holds a bin step, the cutoff -- hence also the reference's read past the row at
+// r = 15.0, src/dfire.rs:338 -- or pairs of bins 0 / 1, i.e. r < 2.5 A, the only ones that can set interface flags).  The LUT
+// code of a cell is the byte offset of its slot.  The marker of the block's row (i, j) is (64 + i * 8 + j) << 50, written into
+// the LDS copy of the row: a lane's 64 adds of a block leave marker bits + sum, and the marker bits say "no flagged pair",
+// WHICH pair, or "several" (dfire_bm.hip, the exact path) -- detection costs the pair loop nothing.
+constexpr int kBmRowSlots = 20;
 constexpr int kBmRowBytes = kBmRowSlots * 8;
-#ifndef LD_BM_WAVES
-#define LD_BM_WAVES 8
-#endif
-constexpr int kBmLig = 8;                    // ligand atoms per job row: a job walks the blocks (kBmLig ligand atoms x 8 receptor atoms) of one
-                                             // half of a ligand subtile -- half the table rows in LDS per wave, twice the waves per CU
-constexpr int kBmSplit = 8 / kBmLig;         // job rows per ligand subtile
-constexpr int kBmRows = 8 * kBmSplit;        // job rows per ligand tile
-constexpr int kBmCubeRows = kBmLig * 8;
-constexpr int kBmHalves = 1;                 // a job walks 8 / kBmHalves of its row's blocks (2 was measured: shorter jobs, twice the set-ups; slower)
-constexpr int kBmJobRows = kBmRows * kBmHalves;   // partial sums per entry
-constexpr int kBmCubeBytes = kBmCubeRows * kBmRowBytes + 16;  // + one zero slot behind the last row
-constexpr uint32_t kBmFlagged = kBmRowBytes;  // LUT code of a flagged cell: slot 0 of the NEXT row = 0.0, above every bin code
-constexpr uint32_t kBmNearCode = 20 * 8;      // codes of bins 0 and 1 (r < 2.5 A, the only pairs that can set interface flags) start here
-__host__ __device__ inline uint32_t bm_slot_of_bin(uint32_t bin) { return bin >= 2 ? bin - 1 : 20 + bin; }
-constexpr int kBmTypes = 170;                // 169 DFIRE types + one all-zero type for padding atoms
-constexpr int kBmWaves = kBmLig == 4 ? 12 : LD_BM_WAVES;  // waves per dfire_bm_pairs workgroup (one workgroup per CU: what its LDS holds)
+constexpr uint32_t kBmMissCode = 8 * 18;     // 144
+constexpr uint32_t kBmFlagged = 8 * 19;      // 152
+constexpr int kBmMarkerShift = 50;           // 64 sums below 2^49 under it, 64 markers of at most 127 above it: 63 bits
+__host__ __device__ inline uint32_t bm_code_of_bin(uint32_t bin) { return 8 * (bin - 2); }   // bins 2..19 -> 0..136
+constexpr int kBmJobRows = 8;                // a job = (tile pair, part of its entries, ligand subtile a): the blocks (a, 0..7); one partial sum per (entry, a)
 constexpr int kBmPartEntries = 1024;         // entries of a tile pair in one job
-constexpr int kBmQueue = 128;                // per wave: pairs waiting for the exact path
-constexpr double kBmFixScale = 1099511627776.0;  // 2^40: fixed-point units of the exact path's sum
+constexpr int kBmCubeRows = 64;              // table rows of a block: 8 ligand x 8 receptor atoms
+constexpr int kBmCubeBytes = kBmCubeRows * kBmRowBytes;
+constexpr int kBmTypes = 170;                // 169 DFIRE types + one all-zero type for padding atoms
+constexpr int kBmWaves = 4;                  // waves per dfire_bm_pairs workgroup: each is compiled with ITS cube's LDS address as a constant
+constexpr int kBmGroupsPerCu = 2;            // workgroups of dfire_bm_pairs per CU (what 160 KB of LDS hold)
+constexpr int kBmWavesPerCu = kBmWaves * kBmGroupsPerCu;
+constexpr int kBmQueuePairs = 8 * kBmPartEntries + 4096 + 512;   // per wave (global memory): 64-bit items, flagged pairs waiting for the exact path: what
+                                             // a job can push (one per item), what it may start with, a round of bm_recheck ...
+constexpr int kBmQueueCap = kBmQueuePairs + 8 * kBmPartEntries + 64;   // ... and behind them (entry, block) items whose flagged pairs have to be found again
+constexpr double kBmFixLimit = 2097152.0;    // |table value| the fixed-point sums take (2^21); the scale is 2^(42 - e), 2^e >= the table's largest |value|:
+                                             // the 64 pairs of a block stay below 2^48, the 512 of an (entry, ligand subtile) partial below 2^51
 constexpr int kBmCounters = 8;               // words behind tp_count, zeroed per launch: (tile pair, part) pairs listed, jobs drawn, entries per
                                              // part, jobs listed; behind them kBmCullQueueWords item counters of dfire_bm_cull
 constexpr int kBmCullQueueWords = 256;
 constexpr int kBmCostClasses = 80;           // jobs are drawn in classes of estimated length, longest first
+constexpr size_t kBmMaxPassPoses = 65536;    // a job keeps its entries' rows of the pass as 16-bit numbers
 
 struct BmModel {
     // receptor (static image in the kappa = 8 frame; no receptor ANM on this path)
@@ -91,10 +99,10 @@ struct BmModel {
     const uint32_t *lig_rowbase = nullptr;      // [n_tiles*64]: byte offset of the atom's type block in `rows`
     const float *lig_tile_sphere = nullptr;     // [n_tiles][4]: centre (local, angstrom) and radius (record units, rounded up) of a sphere around the tile
     // tables
-    const double *rows = nullptr;               // [kBmTypes lig][kBmTypes rec][kBmRowSlots]
-    const uint8_t *lut = nullptr;               // kBmLutBytes codes, cell' = floor(kBmCellMax + 1/2 - 64 d2)
-    const uint8_t *rec_sub_tracked = nullptr;   // [rec subtiles]: 1 = holds an atom with a flag slot
-    const uint8_t *lig_sub_tracked = nullptr;   // [lig subtiles]
+    const long long *rows = nullptr;            // [kBmTypes lig][kBmTypes rec][kBmRowSlots], fixed point
+    const long long *rows_ones = nullptr;       // the same with 1 in every bin's slot: a counting launch sums pairs
+    double fix_scale = 0.0;                     // fixed-point units per unit of the potential
+    const uint8_t *lut = nullptr;               // kBmLutBytes codes, cell' = floor(kBmCellZero + 1/2 - 64 d2)
     const uint8_t *lut_full = nullptr;          // the same without elided zero bins (counting launches)
     const double *table = nullptr;              // 2 x 2 x 4 patches (dfire_tiled.hpp): the exact path's table
     const double *bin_step = nullptr;
@@ -112,32 +120,31 @@ struct BmLaunch {
     const uint8_t *active = nullptr;
     const uint32_t *pose_list = nullptr;   // GSO: compacted rows + device-side count (both null for a plain batch)
     const uint32_t *pose_count = nullptr;
-    size_t first = 0;                      // this launch covers listed rows [first, first + n_poses)
+    size_t first = 0;                      // this pass covers listed rows [first, first + n_poses); row r of the pass = listed row first + r
     size_t n_poses = 0;
     size_t cap = 0;                        // entries per tile pair the workspace has room for (>= n_poses)
-    // workspace
-    float *rt = nullptr;                   // [pose][12]
+    int count_mode = 0;                    // 1: a counting launch -- full LUT, rows of ones, the sums are in-cutoff pair counts (-> count_partial)
+    // workspace of the pass; "row" = row of the pass
+    float *rt = nullptr;                   // [row][12]: the pose as an f32 affine map
     uint32_t *tp_count = nullptr;          // [n_tile_pairs], zeroed per launch
-    uint32_t *ent_pose = nullptr;          // [tile pair][cap]
+    uint32_t *ent_row = nullptr;           // [tile pair][cap]
     unsigned long long *ent_mask = nullptr;  // [tile pair][cap]
-    float *ent_rt = nullptr;               // [tile pair][cap][12]: the entry's pose as the f32 affine map
-    double *ent_partial = nullptr;         // [tile pair][kBmJobRows][cap]
-    uint32_t *ent_count = nullptr;         // [tile pair][kBmJobRows][cap] or nullptr (counting launches)
+    long long *ent_partial = nullptr;      // [tile pair][kBmJobRows][cap], fixed point
     uint32_t *jobs = nullptr;              // [(tile pair, part)][2]: tile pair, first entry; written by dfire_bm_plan
     uint32_t *job_count = nullptr;         // [kBmCounters], zeroed per launch: (tile pair, part) pairs listed, jobs drawn (job_next = job_count + 1),
-                                           // entries per part, jobs listed in job_order, workgroups of dfire_bm_order done
+                                           // entries per part, jobs listed in job_order
     uint32_t *job_next = nullptr;
     uint32_t *job_cost = nullptr;          // [(tile pair, part)][kBmJobRows]: estimated length of the job (0: no block of that row in any entry)
     uint32_t *job_order = nullptr;         // the jobs ((tile pair, part) index * kBmJobRows + row) that have work, longest first
-    int pairs_groups = 0;                  // workgroups of dfire_bm_pairs (0: one per CU of an MI355X)
-    unsigned long long *debug = nullptr;   // diagnostics (LIGHTDOCK_BM_DEBUG): per wave of dfire_bm_pairs {start, end (100 MHz), jobs, batches}
-    uint32_t *vis_count = nullptr;         // [pose][lig tiles]
-    unsigned long long *vis_entry = nullptr;  // [pose][lig tiles][rec tiles]: receptor tile << 48 | (ligand subtile, half of its blocks) pairs with a block << 32 | entry
-    uint32_t *tile_tested = nullptr;       // [pose][lig tiles]: 8x8 blocks let through (diagnostics) or nullptr
-    long long *exact_fix = nullptr;        // [pose], zeroed per launch: exact-path sum in 2^-40 units
-    uint32_t *exact_count = nullptr;       // [pose], zeroed per launch, or nullptr
-    uint32_t *exact_pairs = nullptr;       // [pose], zeroed: pairs recomputed in f64 (diagnostics) or nullptr
-    uint32_t *flags = nullptr;             // [pose][rec words + lig words], zeroed per launch
+    unsigned long long *queue = nullptr;   // [waves of dfire_bm_pairs][kBmQueueCap]: pairs waiting for the exact path
+    int pairs_groups = 0;                  // CUs dfire_bm_pairs / dfire_bm_cull may fill (0: the 256 of an MI355X)
+    unsigned long long *debug = nullptr;   // diagnostics (LIGHTDOCK_BM_DEBUG): per wave of dfire_bm_pairs {start, end (100 MHz), jobs, batches, ...}
+    uint32_t *vis_count = nullptr;         // [row][lig tiles]
+    unsigned long long *vis_entry = nullptr;  // [row][lig tiles][rec tiles]: receptor tile << 48 | ligand subtiles with a block << 32 | entry
+    uint32_t *tile_tested = nullptr;       // [row][lig tiles]: 8x8 blocks let through (diagnostics) or nullptr
+    long long *exact_fix = nullptr;        // [row], zeroed by dfire_bm_pose: exact-path sum, fixed point
+    uint32_t *exact_pairs = nullptr;       // [row]: pairs recomputed in f64 (diagnostics) or nullptr
+    uint32_t *flags = nullptr;             // [pose][rec words + lig words], zeroed by dfire_bm_pose
     double *partial = nullptr;             // out: [pose][1][2] for pose_energy_finish
     uint32_t *count_partial = nullptr;     // out: [pose][1] or nullptr
     uint32_t *tested_partial = nullptr;    // out: [pose][1] or nullptr

@@ -661,16 +661,17 @@ double dfire_bm_error_bound(double ubound, double lig_extent) {
 // reaches (E < 0) reading cell' 0; the cells above kBmCellZero are what an error of up to 8 cells can turn a distance near 0
 // into.  Cell' k' = kBmCellZero - k holds the pairs with 64 d2 within (k - 1/2 - eps, k + 1/2 + eps),
 // i.e. a true 4 d2 within ((k - 1/2 - eps) / 16, (k + 1/2 + eps) / 16).  A cell with ONE answer for that whole interval
-// carries the bin's slot in the block's table rows (bm_slot_of_bin(bin) * 8; 0 = "miss" beyond the cutoff or a bin that is
-// zero for the whole complex); a cell with a bin step or the cutoff inside is flagged: the kernel reads 0.0 and recomputes
-// the pair in f64.  The interface distance (src/dfire.rs:339) lies inside bin 1: the kernel sends the pairs of bins 0 and 1
-// of a block that has an atom with a flag slot to the exact path as well, for their flags only.
+// carries the byte offset of the bin's slot in the block's table rows (bm_code_of_bin(bin) = 8 (bin - 2) for bins 2..19;
+// kBmMissCode = "miss" beyond the cutoff or a bin that is zero for the whole complex); a cell with a bin step or the cutoff
+// inside is flagged (kBmFlagged, the slot of the marker): the pair is recomputed in f64.  So is every cell that can hold a
+// pair of bins 0 or 1 (r < 2.5 A): those are the only pairs that can set interface flags (the interface distance,
+// src/dfire.rs:339, lies inside bin 1), which is the exact path's business, and they are few.
 std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins) {
     const DfireBinning b = build_dfire_binning();
     const double iface_scaled = 4.0 * dfire_interface_d2();
     if (!(iface_scaled < 4.0 * b.step[2] && iface_scaled >= 4.0 * b.step[1]))
         throw Error(LD_ERR_INVALID, "DFIRE block-major LUT: the interface distance is not inside bin 1");
-    std::vector<uint8_t> codes(kBmLutBytes, 0);
+    std::vector<uint8_t> codes(kBmLutBytes, (uint8_t)kBmMissCode);
     for (int k = kBmCellZero - (kBmLutBytes - 1); k <= kBmCellZero; k++) {
         uint8_t &code = codes[kBmCellZero - k];
         const double ilo = (k - 0.5 - eps_cells) / kBmCells, ihi = (k + 0.5 + eps_cells) / kBmCells;
@@ -682,16 +683,15 @@ std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins) {
             if (at < ilo) base_bin = s;
             else if (at <= ihi) flagged = true;
         }
-        if (flagged) {
+        if (flagged || base_bin < 2 || base_bin > 19) {
             code = (uint8_t)kBmFlagged;
             continue;
         }
         if (dfire_bin_reference(std::max(ilo, 0.0) / 4.0) != base_bin || dfire_bin_reference(ihi / 4.0) != base_bin)
             throw Error(LD_ERR_INVALID, "DFIRE block-major LUT self-check failed in cell " + std::to_string(k));
-        // (bins 0 and 1 are never elided: a block with tracked atoms recognises its flag-setting pairs by their codes)
-        code = base_bin >= 2 && ((zero_bins >> base_bin) & 1u) ? 0 : (uint8_t)(bm_slot_of_bin((uint32_t)base_bin) * 8);
+        code = ((zero_bins >> base_bin) & 1u) ? (uint8_t)kBmMissCode : (uint8_t)bm_code_of_bin((uint32_t)base_bin);
     }
-    if (codes[0] != 0) throw Error(LD_ERR_INVALID, "DFIRE block-major LUT: the far cell is not a miss");
+    if (codes[0] != kBmMissCode) throw Error(LD_ERR_INVALID, "DFIRE block-major LUT: the far cell is not a miss");
     return codes;
 }
 
@@ -714,7 +714,11 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     if (use_anm_ && (desc.receptor.num_anm > 0 || desc.ligand.num_anm > 0)) return;
     if (rec_anm_per_pose_) return;
     const TiledSoA &rec = tiled_rec_soa_, &lig = tiled_lig_soa_;
-    if (rec.n_tiles > 255 || lig.n_tiles > 4096) return;  // an entry names its receptor tile in 8 bits
+    if (rec.n_tiles > 1024 || lig.n_tiles > 1024) return;  // an item of the exact path names its atoms in 16 bits each
+    // The exact path's values reach a pose's sum as 2^-40 fixed point (dfire_bm.hpp): a table that could overflow it, or
+    // holds a value the reference would carry as inf / NaN (src/dfire.rs:338), stays with the pose-major kernels.
+    for (size_t i = 0; i < LD_DFIRE_TABLE_LEN; i++)
+        if (!(std::fabs(desc.potential[i]) <= kBmFixLimit)) return;
     double centre[3], half;
     frame_of_receptor(desc.receptor, centre, &half);
     // The frame holds the receptor's box + 16 A: a ligand atom outside it is beyond the cutoff of every receptor atom.
@@ -754,17 +758,6 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     }
     M.lut = arena_.upload(build_bm_lut(eps, packed_zero_bins_));
     M.lut_full = packed_zero_bins_ ? arena_.upload(build_bm_lut(eps, 0)) : M.lut;  // counting launches count every pair
-    {   // subtiles that hold an atom with an interface-flag slot (restraint atoms, membrane beads)
-        auto tracked = [](const TiledSoA &m) {
-            std::vector<uint8_t> t(m.hslot.size() / 8, 0);
-            for (size_t i = 0; i < m.hslot.size(); i++)
-                if (m.hslot[i] >= 0) t[i / 8] = 1;
-            return t;
-        };
-        M.rec_sub_tracked = arena_.upload(tracked(rec));
-        M.lig_sub_tracked = arena_.upload(tracked(lig));
-    }
-
     {   // receptor image in this frame, by the kernel that builds the packed kernel's
         const size_t pad = (size_t)rec.n_tiles * 64;
         PackedRecPair *pairs = static_cast<PackedRecPair *>(arena_.alloc_bytes(pad / 2 * sizeof(PackedRecPair)));
@@ -828,23 +821,32 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
         }
         M.lig_tile_sphere = arena_.upload(sphere);
     }
-    {   // rows[l][r][0] = 0.0; rows[l][r][bm_slot_of_bin(b)] = potential[r * 3380 + l * 20 + b], b = 0..20 (20 = the read past the row, src/dfire.rs:338)
-        std::vector<double> rows((size_t)kBmTypes * kBmTypes * kBmRowSlots, 0.0);
-        for (uint32_t l = 0; l < 169; l++)
-            for (uint32_t r = 0; r < 169; r++)
-                for (uint32_t b = 0; b <= 20; b++) {
-                    const size_t at = (size_t)r * kDfireRowStride + l * 20 + b;
-                    if (at < LD_DFIRE_TABLE_LEN) rows[((size_t)l * kBmTypes + r) * kBmRowSlots + bm_slot_of_bin(b)] = desc.potential[at];
+    {   // rows[l][r][b - 2] = potential[r * 3380 + l * 20 + b] in fixed point, b = 2..19; slot 18 = 0, slot 19: the kernel's marker
+        double vmax = 1.0;
+        for (size_t i = 0; i < LD_DFIRE_TABLE_LEN; i++) vmax = std::max(vmax, std::fabs(desc.potential[i]));
+        int e = 0;
+        while (std::ldexp(1.0, e) < vmax) e++;
+        M.fix_scale = std::ldexp(1.0, 42 - e);   // the 64 pairs of a block stay below 2^48: under the markers (dfire_bm.hpp)
+        std::vector<long long> rows((size_t)kBmTypes * kBmTypes * kBmRowSlots, 0), ones(rows.size(), 0);
+        for (uint32_t l = 0; l < (uint32_t)kBmTypes; l++)
+            for (uint32_t r = 0; r < (uint32_t)kBmTypes; r++) {
+                long long *row = &rows[((size_t)l * kBmTypes + r) * kBmRowSlots], *one = &ones[((size_t)l * kBmTypes + r) * kBmRowSlots];
+                if (l >= 169 || r >= 169) continue;   // the all-zero type of padding atoms
+                for (uint32_t b = 2; b <= 19; b++) {
+                    row[b - 2] = std::llrint(desc.potential[(size_t)r * kDfireRowStride + l * 20 + b] * M.fix_scale);
+                    one[b - 2] = 1;
                 }
+            }
         M.rows = arena_.upload(rows);
+        M.rows_ones = arena_.upload(ones);
     }
-    // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x (60 + 12 per job row) bytes
+    // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x (12 + 8 per job row + 8 in the gather list) bytes
     const size_t tile_pairs = (size_t)rec.n_tiles * lig.n_tiles;
-    size_t chunk = ((size_t)4 << 30) / ((60 + 12 * kBmJobRows) * tile_pairs);   // two such workspaces exist (two passes in flight)
-    chunk = std::max<size_t>(kBmPartEntries, chunk / kBmPartEntries * kBmPartEntries);
+    size_t chunk = ((size_t)4 << 30) / ((20 + 8 * kBmJobRows) * tile_pairs);   // a second such workspace exists while two passes are in flight
+    chunk = std::min<size_t>(kBmMaxPassPoses, std::max<size_t>(kBmPartEntries, chunk / kBmPartEntries * kBmPartEntries));
     if (const char *e = std::getenv("LIGHTDOCK_BM_CHUNK")) {
         const long v = std::atol(e);
-        if (v >= 1) chunk = (size_t)v;
+        if (v >= 1) chunk = std::min<size_t>((size_t)v, kBmMaxPassPoses);
     }
     bm_chunk_ = chunk;
     {
@@ -866,11 +868,16 @@ size_t Scorer::bm_pass_poses(size_t n) const {
     return std::min(n, bm_chunk_);
 }
 
+// Workspace sets of a block-major batch: one per pass in flight (two when the batch needs several passes and the second
+// stream exists).  Everything but the per-pose outputs (flags, partial sums) is indexed by the row of the pass.
+size_t Scorer::bm_sets(size_t n) const { return n > bm_pass_poses(n) && bm_aux_stream_ != nullptr ? 2 : 1; }
+
 void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_t *d_active, bool counts, const uint32_t *d_list,
                     const uint32_t *d_count) {
-    const size_t tile_pairs = (size_t)bm_.lig.n_tiles * bm_.rec_n_tiles;
+    const size_t n_lt = (size_t)bm_.lig.n_tiles, tile_pairs = n_lt * bm_.rec_n_tiles;
     const size_t cap = bm_pass_poses(n);
-    const size_t jobs_per_lane = tile_pairs * (cap / 64 + 1) * 2;
+    const size_t parts = tile_pairs * (cap / 64 + 1);   // at most entries / 64 + tile pairs (tile pair, part) pairs
+    const size_t waves = (size_t)n_cus_ * kBmWavesPerCu;
     BmLaunch t;
     t.m = bm_;
     t.poses = d_poses;
@@ -879,29 +886,22 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
     t.pose_list = d_list;
     t.pose_count = d_list ? d_count : nullptr;
     t.cap = cap;
-    t.rt = static_cast<float *>(ws_bm_rt_.ptr);
     t.pairs_groups = n_cus_;
-    t.vis_count = static_cast<uint32_t *>(ws_bm_vis_count_.ptr);
-    t.vis_entry = static_cast<unsigned long long *>(ws_bm_vis_entry_.ptr);
-    t.exact_fix = static_cast<long long *>(ws_bm_exact_fix_.ptr);
     t.flags = static_cast<uint32_t *>(ws_flags_.ptr);
     t.partial = static_cast<double *>(ws_partial_.ptr);
     if (counts) {
-        t.tile_tested = static_cast<uint32_t *>(ws_bm_tile_tested_.ptr);
-        t.exact_count = static_cast<uint32_t *>(ws_bm_exact_count_.ptr);
-        t.exact_pairs = static_cast<uint32_t *>(ws_bm_exact_pairs_.ptr);
         t.count_partial = static_cast<uint32_t *>(ws_counts_.ptr);
         t.tested_partial = static_cast<uint32_t *>(ws_tested_.ptr);
         t.exact_partial = static_cast<uint32_t *>(ws_exact_.ptr);
     }
     const char *dbg = std::getenv("LIGHTDOCK_BM_DEBUG");
     if (dbg) {
-        ws_bm_debug_.reserve((size_t)n_cus_ * kBmWaves * 8 * sizeof(unsigned long long));
+        ws_bm_debug_.reserve(waves * 8 * sizeof(unsigned long long));
         t.debug = static_cast<unsigned long long *>(ws_bm_debug_.ptr);
     }
     // Passes of at most `cap` poses (poses are independent), alternating between this handle's stream and a second
     // one: fork behind what the stream holds so far, join before what follows.
-    const bool two_lanes = n > cap && bm_aux_stream_ != nullptr;
+    const bool two_lanes = bm_sets(n) == 2;
     if (two_lanes) {
         hip_check(hipEventRecord(bm_fork_, stream_), "hipEventRecord");
         hip_check(hipStreamWaitEvent(bm_aux_stream_, bm_fork_, 0), "hipStreamWaitEvent");
@@ -909,25 +909,35 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
     int lane = 0;
     for (size_t off = 0; off < n; off += cap, lane ^= 1) {
         hipStream_t st = lane && two_lanes ? bm_aux_stream_ : stream_;
-        const size_t w = (size_t)lane;   // workspace set
+        const size_t w = two_lanes ? (size_t)lane : 0;   // workspace set
         t.first = off;
         t.n_poses = std::min(cap, n - off);
+        t.rt = static_cast<float *>(ws_bm_rt_.ptr) + w * cap * 12;
         t.tp_count = static_cast<uint32_t *>(ws_bm_tp_count_.ptr) + w * (tile_pairs + kBmCounters + kBmCullQueueWords);
         t.job_count = t.tp_count + tile_pairs;
         t.job_next = t.tp_count + tile_pairs + 1;
-        t.jobs = static_cast<uint32_t *>(ws_bm_jobs_.ptr) + w * jobs_per_lane;
-        t.job_cost = static_cast<uint32_t *>(ws_bm_job_cost_.ptr) + w * jobs_per_lane / 2 * kBmJobRows;
-        t.job_order = static_cast<uint32_t *>(ws_bm_job_order_.ptr) + w * jobs_per_lane / 2 * kBmJobRows;
-        t.ent_pose = static_cast<uint32_t *>(ws_bm_ent_pose_.ptr) + w * tile_pairs * cap;
+        t.jobs = static_cast<uint32_t *>(ws_bm_jobs_.ptr) + w * parts * 2;
+        t.job_cost = static_cast<uint32_t *>(ws_bm_job_cost_.ptr) + w * parts * kBmJobRows;
+        t.job_order = static_cast<uint32_t *>(ws_bm_job_order_.ptr) + w * parts * kBmJobRows;
+        t.queue = static_cast<unsigned long long *>(ws_bm_queue_.ptr) + w * waves * kBmQueueCap;
+        t.ent_row = static_cast<uint32_t *>(ws_bm_ent_row_.ptr) + w * tile_pairs * cap;
         t.ent_mask = static_cast<unsigned long long *>(ws_bm_ent_mask_.ptr) + w * tile_pairs * cap;
-        t.ent_rt = static_cast<float *>(ws_bm_ent_rt_.ptr) + w * tile_pairs * cap * 12;
-        t.ent_partial = static_cast<double *>(ws_bm_ent_partial_.ptr) + w * tile_pairs * kBmJobRows * cap;
-        t.ent_count = counts ? static_cast<uint32_t *>(ws_bm_ent_count_.ptr) + w * tile_pairs * kBmJobRows * cap : nullptr;
-        hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + kBmCounters + kBmCullQueueWords) * sizeof(uint32_t), st), "hipMemsetAsync(tile pair counts)");
-        hip_check(launch_bm_pose(t, st), "launch dfire_bm_pose");
-        hip_check(launch_bm_cull(t, st), "launch dfire_bm_cull");
-        hip_check(launch_bm_pairs(t, st), "launch dfire_bm_pairs");
-        hip_check(launch_bm_gather(t, st), "launch dfire_bm_gather");
+        t.ent_partial = static_cast<long long *>(ws_bm_ent_partial_.ptr) + w * tile_pairs * kBmJobRows * cap;
+        t.vis_count = static_cast<uint32_t *>(ws_bm_vis_count_.ptr) + w * cap * n_lt;
+        t.vis_entry = static_cast<unsigned long long *>(ws_bm_vis_entry_.ptr) + w * cap * tile_pairs;
+        t.exact_fix = static_cast<long long *>(ws_bm_exact_fix_.ptr) + w * cap;
+        // With pair counts wanted the sequence runs twice: first as a counting launch (the same kernels over rows of ones and the
+        // full LUT: the sums are the in-cutoff pair counts), then for the energies.
+        for (int mode = counts ? 1 : 0; mode >= 0; mode--) {
+            t.count_mode = mode;
+            t.tile_tested = mode ? static_cast<uint32_t *>(ws_bm_tile_tested_.ptr) + w * cap * n_lt : nullptr;
+            t.exact_pairs = mode ? static_cast<uint32_t *>(ws_bm_exact_pairs_.ptr) + w * cap : nullptr;
+            hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + kBmCounters + kBmCullQueueWords) * sizeof(uint32_t), st), "hipMemsetAsync(tile pair counts)");
+            hip_check(launch_bm_pose(t, st), "launch dfire_bm_pose");
+            hip_check(launch_bm_cull(t, st), "launch dfire_bm_cull");
+            hip_check(launch_bm_pairs(t, st), "launch dfire_bm_pairs");
+            hip_check(launch_bm_gather(t, st), "launch dfire_bm_gather");
+        }
     }
     if (two_lanes) {
         hip_check(hipEventRecord(bm_join_, bm_aux_stream_), "hipEventRecord");
@@ -935,7 +945,7 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
     }
     if (dbg) {   // diagnostics: wave lifetimes of the last pass, one text line per wave
         hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-        std::vector<unsigned long long> h((size_t)n_cus_ * kBmWaves * 8);
+        std::vector<unsigned long long> h(waves * 8);
         hip_check(hipMemcpy(h.data(), t.debug, h.size() * 8, hipMemcpyDeviceToHost), "D2H debug");
         if (FILE *f = std::fopen(dbg, "w")) {
             for (size_t i = 0; i < h.size(); i += 8)
@@ -1010,8 +1020,8 @@ Scorer::~Scorer() {
     ws_rec_tile_.release();
     ws_rec_pairs_.release();
     ws_exact_.release();
-    for (DeviceBuffer *b : {&ws_bm_rt_, &ws_bm_tp_count_, &ws_bm_ent_pose_, &ws_bm_jobs_, &ws_bm_job_cost_, &ws_bm_job_order_, &ws_bm_ent_mask_, &ws_bm_ent_rt_, &ws_bm_ent_partial_, &ws_bm_ent_count_, &ws_bm_vis_count_,
-                            &ws_bm_vis_entry_, &ws_bm_tile_tested_, &ws_bm_exact_fix_, &ws_bm_exact_count_, &ws_bm_exact_pairs_})
+    for (DeviceBuffer *b : {&ws_bm_rt_, &ws_bm_tp_count_, &ws_bm_ent_row_, &ws_bm_jobs_, &ws_bm_job_cost_, &ws_bm_job_order_, &ws_bm_ent_mask_, &ws_bm_queue_, &ws_bm_ent_partial_, &ws_bm_vis_count_,
+                            &ws_bm_vis_entry_, &ws_bm_tile_tested_, &ws_bm_exact_fix_, &ws_bm_exact_pairs_})
         b->release();
     ws_poses_.release();
     ws_energies_.release();
@@ -1020,9 +1030,9 @@ Scorer::~Scorer() {
 uint64_t Scorer::workspace_generation() const {
     return ws_partial_.generation + ws_flags_.generation + ws_counts_.generation + ws_tested_.generation + ws_exact_.generation +
            ws_rec_atoms_.generation + ws_rec_sub_.generation + ws_rec_tile_.generation + ws_rec_pairs_.generation + ws_bm_rt_.generation +
-           ws_bm_tp_count_.generation + ws_bm_ent_pose_.generation + ws_bm_jobs_.generation + ws_bm_job_cost_.generation + ws_bm_job_order_.generation + ws_bm_ent_mask_.generation + ws_bm_ent_rt_.generation + ws_bm_ent_partial_.generation +
-           ws_bm_ent_count_.generation + ws_bm_vis_count_.generation + ws_bm_vis_entry_.generation + ws_bm_tile_tested_.generation +
-           ws_bm_exact_fix_.generation + ws_bm_exact_count_.generation + ws_bm_exact_pairs_.generation;
+           ws_bm_tp_count_.generation + ws_bm_ent_row_.generation + ws_bm_jobs_.generation + ws_bm_job_cost_.generation + ws_bm_job_order_.generation + ws_bm_ent_mask_.generation + ws_bm_queue_.generation + ws_bm_ent_partial_.generation +
+           ws_bm_vis_count_.generation + ws_bm_vis_entry_.generation + ws_bm_tile_tested_.generation +
+           ws_bm_exact_fix_.generation + ws_bm_exact_pairs_.generation;
 }
 
 void Scorer::reserve_workspace(size_t n_poses, bool counts) {
@@ -1036,25 +1046,24 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         ws_exact_.reserve(n_poses * chunks * sizeof(uint32_t));
     }
     if (use_bm_) {
-        const size_t n = n_poses, n_lt = (size_t)bm_.lig.n_tiles, n_rt = (size_t)bm_.rec_n_tiles, tile_pairs = n_lt * n_rt;
-        const size_t cap = bm_pass_poses(n) * 2;   // two passes in flight (run_bm), each with its own entry workspace
-        ws_bm_rt_.reserve(n * 12 * sizeof(float));
-        ws_bm_tp_count_.reserve(2 * (tile_pairs + kBmCounters + kBmCullQueueWords) * sizeof(uint32_t));   // + the launch's counters
-        ws_bm_jobs_.reserve(2 * (tile_pairs * (cap / 2 / 64 + 1)) * 2 * sizeof(uint32_t));   // at most entries / 64 + tile pairs parts
-        ws_bm_job_cost_.reserve(2 * (tile_pairs * (cap / 2 / 64 + 1)) * kBmJobRows * sizeof(uint32_t));
-        ws_bm_job_order_.reserve(2 * (tile_pairs * (cap / 2 / 64 + 1)) * kBmJobRows * sizeof(uint32_t));
-        ws_bm_ent_pose_.reserve(tile_pairs * cap * sizeof(uint32_t));
-        ws_bm_ent_mask_.reserve(tile_pairs * cap * sizeof(unsigned long long));
-        ws_bm_ent_rt_.reserve(tile_pairs * cap * 12 * sizeof(float));
-        ws_bm_ent_partial_.reserve(tile_pairs * kBmJobRows * cap * sizeof(double));
-        ws_bm_vis_count_.reserve(n * n_lt * sizeof(uint32_t));
-        ws_bm_vis_entry_.reserve(n * tile_pairs * sizeof(unsigned long long));
-        ws_bm_exact_fix_.reserve(n * sizeof(long long));
+        const size_t n_lt = (size_t)bm_.lig.n_tiles, n_rt = (size_t)bm_.rec_n_tiles, tile_pairs = n_lt * n_rt;
+        const size_t cap = bm_pass_poses(n_poses), sets = bm_sets(n_poses);   // a second set only while two passes are in flight
+        const size_t parts = tile_pairs * (cap / 64 + 1), waves = (size_t)n_cus_ * kBmWavesPerCu;
+        ws_bm_rt_.reserve(sets * cap * 12 * sizeof(float));
+        ws_bm_tp_count_.reserve(sets * (tile_pairs + kBmCounters + kBmCullQueueWords) * sizeof(uint32_t));   // + the launch's counters
+        ws_bm_jobs_.reserve(sets * parts * 2 * sizeof(uint32_t));
+        ws_bm_job_cost_.reserve(sets * parts * kBmJobRows * sizeof(uint32_t));
+        ws_bm_job_order_.reserve(sets * parts * kBmJobRows * sizeof(uint32_t));
+        ws_bm_queue_.reserve(sets * waves * kBmQueueCap * sizeof(unsigned long long));
+        ws_bm_ent_row_.reserve(sets * tile_pairs * cap * sizeof(uint32_t));
+        ws_bm_ent_mask_.reserve(sets * tile_pairs * cap * sizeof(unsigned long long));
+        ws_bm_ent_partial_.reserve(sets * tile_pairs * kBmJobRows * cap * sizeof(long long));
+        ws_bm_vis_count_.reserve(sets * cap * n_lt * sizeof(uint32_t));
+        ws_bm_vis_entry_.reserve(sets * cap * tile_pairs * sizeof(unsigned long long));
+        ws_bm_exact_fix_.reserve(sets * cap * sizeof(long long));
         if (counts) {
-            ws_bm_ent_count_.reserve(tile_pairs * kBmJobRows * cap * sizeof(uint32_t));   // (cap covers both passes in flight)
-            ws_bm_tile_tested_.reserve(n * n_lt * sizeof(uint32_t));
-            ws_bm_exact_count_.reserve(n * sizeof(uint32_t));
-            ws_bm_exact_pairs_.reserve(n * sizeof(uint32_t));
+            ws_bm_tile_tested_.reserve(sets * cap * n_lt * sizeof(uint32_t));
+            ws_bm_exact_pairs_.reserve(sets * cap * sizeof(uint32_t));
         }
     }
 }

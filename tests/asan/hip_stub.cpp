@@ -83,26 +83,32 @@ hipError_t launch_dfire_packed(const PackedLaunch &t, hipStream_t) {
 }
 size_t bm_pairs_lds_bytes() { return 0; }
 hipError_t launch_bm_pose(const BmLaunch &t, hipStream_t) {
-    if (t.n_poses && t.rt) t.rt[12 * (t.first + t.n_poses) - 1] = 0.f;   // last slot of the affine maps
+    if (t.n_poses && t.rt) t.rt[12 * t.n_poses - 1] = 0.f;   // last slot of the pass's affine maps (the workspace of a pass goes by row)
     return hipSuccess;
 }
 hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t) {
     const size_t tile_pairs = (size_t)t.m.lig.n_tiles * t.m.rec_n_tiles;
     if (t.n_poses) {
-        t.ent_pose[tile_pairs * t.cap - 1] = 0;
+        t.ent_row[tile_pairs * t.cap - 1] = 0;
         t.ent_mask[tile_pairs * t.cap - 1] = 0;
-        t.vis_entry[(t.first + t.n_poses) * tile_pairs - 1] = 0ull;
-        t.vis_count[(t.first + t.n_poses) * (size_t)t.m.lig.n_tiles - 1] = 0;
+        t.vis_entry[t.n_poses * tile_pairs - 1] = 0ull;
+        t.vis_count[t.n_poses * (size_t)t.m.lig.n_tiles - 1] = 0;
+        t.exact_fix[t.n_poses - 1] = 0;
     }
     return hipSuccess;
 }
 hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t) {
     const size_t tile_pairs = (size_t)t.m.lig.n_tiles * t.m.rec_n_tiles;
-    if (t.n_poses) t.ent_partial[tile_pairs * kBmJobRows * t.cap - 1] = 0.0;
+    if (t.n_poses) {
+        t.ent_partial[tile_pairs * kBmJobRows * t.cap - 1] = 0;
+        t.queue[(size_t)t.pairs_groups * kBmWavesPerCu * kBmQueueCap - 1] = 0ull;
+        t.job_order[tile_pairs * (t.cap / 64 + 1) * kBmJobRows - 1] = 0u;
+    }
     return hipSuccess;
 }
 hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t) {
-    if (t.n_poses) t.partial[2 * (t.first + t.n_poses) - 1] = 0.0;
+    if (t.n_poses && !t.count_mode) t.partial[2 * (t.first + t.n_poses) - 1] = 0.0;
+    if (t.n_poses && t.count_mode) t.count_partial[t.first + t.n_poses - 1] = 0u;
     return hipSuccess;
 }
 hipError_t launch_packed_prepare(const PackedPrepareLaunch &p, hipStream_t) {

@@ -21,7 +21,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for p in sorted(glob.glob(out+'/p*/*/*counter_collection.csv')):
     for r in csv.DictReader(open(p)):
         k=r['Kernel_Name']
-        for short in ('dfire_bm_pairs<false','dfire_bm_cull<false','dfire_bm_gather<false','dfire_packed_pairs<false'):
+        for short in ('dfire_bm_pairs<false','dfire_bm_cull<false','dfire_bm_gather','dfire_packed_pairs<false'):
             if short in k: agg[short][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,d in agg.items():
     for c,v in sorted(d.items()): print('%-26s %-34s n=%d mean=%.5g'%(k,c,len(v),sum(v)/len(v)))
