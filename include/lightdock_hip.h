@@ -139,13 +139,11 @@ int ld_dfire_packed_lut(int cells_per_unit, double ubound, uint32_t *words_out, 
  * computes E = 14583.5 - 64 d2 in f32 (error below eps_cells / 2, which depends on the frame `ubound` in record units
  * of 1/8 A and on the ligand's largest |local coordinate| `lig_extent` in A) and reads codes_out[floor(E)], E < 0 reading
  * cell 0:
- *   code 144                     every f64 d2 that can produce this cell is beyond the cutoff (src/dfire.rs:334)
- *   code 8 * (bin - 2), bin 2..19 every such d2 has that bin (src/dfire.rs:336-337) and is inside the cutoff: the byte offset
- *                                of the bin's slot in a table row of the kernel
- *   code 152                     flagged (the slot of the row's marker): the pair is recomputed in f64 -- a bin step or
- *                                the cutoff inside the cell's interval (hence r = 15.0 exactly, the reference's read past the
- *                                row, :338), or a distance below 2.5 A (bins 0 and 1: the pairs that can set interface
- *                                flags, src/dfire.rs:339)
+ *   code 160                     every f64 d2 that can produce this cell is beyond the cutoff (src/dfire.rs:334)
+ *   code 8 * bin, bin 0..19      every such d2 has that bin (src/dfire.rs:336-337) and is inside the cutoff: the byte offset of
+ *                                the bin's slot in a table row of the kernel
+ *   code 168                     flagged (the slot of the row's marker): the pair is recomputed in f64 -- a bin step or the
+ *                                cutoff inside the cell's interval (hence r = 15.0 exactly, the reference's read past the row, :338)
  * codes_out: 14592 entries. */
 int ld_dfire_bm_lut(double ubound, double lig_extent, uint8_t *codes_out, double *eps_cells_out);
 /* The atom order the tiled DFIRE kernel uses (host-side, no GPU): order_out[slot] = original atom

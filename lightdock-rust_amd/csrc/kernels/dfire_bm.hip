@@ -26,6 +26,9 @@ namespace {
 typedef const __attribute__((address_space(4))) BmLaunch BmArgs;
 #define LD_BM_ARGS ((BmArgs *)__builtin_amdgcn_kernarg_segment_ptr())
 
+#ifndef LD_BM_EXPERIMENT
+#define LD_BM_EXPERIMENT 0
+#endif
 #ifndef LD_BM_CULL_WAVES
 #define LD_BM_CULL_WAVES 4
 #endif
@@ -640,6 +643,7 @@ __device__ __forceinline__ void bm_exact_pairs(BmArgs *T, unsigned long long *qu
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (!act[u]) continue;
+            if (LD_BM_EXPERIMENT == 2 && pr[u][0] + lc[u][0] + rc[u][0] != 1.2345e300) continue;
             if (T->exact_pairs) atomicAdd(T->exact_pairs + row[u], 1u);
             // the ligand atom as the reference poses it (src/dfire.rs:282-302: pose_ligand_atom's operations), then exact_pair's
             const Quat q{pr[u][3], pr[u][4], pr[u][5], pr[u][6]};
@@ -710,6 +714,8 @@ __device__ __forceinline__ uint32_t bm_recheck(BmArgs *T, const unsigned char *l
         l2[i] = __builtin_fmaf(lx[i], lx[i], __builtin_fmaf(ly[i], ly[i], lz[i] * lz[i]));
     }
     const float *rec = reinterpret_cast<const float *>(T->m.rec_pairs + (size_t)RT * 32 + b * 4);   // 4 records: x0 x1 y0 y1 z0 z1 . .
+    // (in a block with tracked atoms the slots of bins 0 and 1 held markers too)
+    const uint32_t near_code = T->m.lig_sub_tracked[ls] != 0 || T->m.rec_sub_tracked[RT * 8 + b] != 0 ? bm_code_of_bin(1) : 0xffffffffu;
 #pragma unroll 1
     for (int q = 0; q < 4; q++) {
 #pragma unroll
@@ -720,7 +726,8 @@ __device__ __forceinline__ uint32_t bm_recheck(BmArgs *T, const unsigned char *l
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const uint32_t cell = bm_cell(Rs, Rz, Ry, Rx, l2[i], lz[i], ly[i], lx[i]);
-                const bool hit = act && lut[cell] == kBmFlagged;
+                const uint32_t code = lut[cell];
+                const bool hit = act && (code == kBmFlagged || (near_code != 0xffffffffu && code <= near_code));
                 const unsigned long long m = __ballot(hit);
                 if (hit) {
                     const uint32_t at = n_pairs + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -812,12 +819,14 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         // (kept in LDS, read back per batch as broadcasts: 24 wave-uniform values in vector registers for the whole job are what
         // pushed the block set-up into scratch)
         if (lane < 8) WS.lig_local[lane] = reinterpret_cast<const float4 *>(T->m.lig_local)[ls * 8 + lane];
-        // table rows of a block -> LDS by LDS-DMA: an instruction copies 6 rows, lane = (row of the six, one of its 10 pieces of
-        // 16 bytes) -- the lane's two numbers are the same for every instruction, 60 lanes take part (piece p of an instruction
-        // lands at its LDS address + 16 p: six rows of 160 bytes, contiguous).  The lane keeps the row block of ligand atom
+        // table rows of a block -> LDS by LDS-DMA: an instruction copies 5 rows, lane = (row of the five, one of its 11 pieces of
+        // 16 bytes) -- the lane's two numbers are the same for every instruction, 55 lanes take part (piece p of an instruction
+        // lands at its LDS address + 16 p: five rows of 176 bytes, contiguous).  The lane keeps the row block of ligand atom
         // lane % 8 (where its type's rows start in the table).
         constexpr int kRowPieces = kBmRowBytes / 16, kDmaRows = 64 / kRowPieces, kDma = (kBmCubeRows + kDmaRows - 1) / kDmaRows;
-        static_assert(kRowPieces == 10 && kDmaRows == 6 && kDma == 11, "six rows per copy");
+        static_assert(kRowPieces == 11 && kDmaRows == 5 && kDma == 13, "five rows per copy");
+        const bool lig_tracked = T->m.lig_sub_tracked[ls] != 0;
+        const uint32_t my_tracked = T->m.rec_sub_tracked[RT * 8 + (lane & 7)];
         const uint32_t lig_rowbase = T->m.lig_rowbase[ls * 8 + (lane & 7)];
         const size_t row_base = (tp * kBmJobRows + (size_t)a) * T->cap + lo;
         const size_t row_base_entry = tp * T->cap + lo;
@@ -837,6 +846,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                         __builtin_amdgcn_global_load_lds((const global_u32 *)(table_rows + src), (lds_u32 *)(S.cube[wave] + t * (kDmaRows * kBmRowBytes)), 16, 0, 0);
                 }
             }
+            const bool tracked = lig_tracked || __builtin_amdgcn_readlane((int)my_tracked, b) != 0;
             constexpr float seed = (float)kBmCellZero + 0.5f;
             // ---- the job's entries that hold block (a, b), in entry order (all 16 chunks' bytes in flight, then the ballots)
             uint32_t n_items = 0;
@@ -924,12 +934,15 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 }
                 // The batch's 64 pairs: dfire_bm_batch.inc (generated, tools/gen_bm_batch_asm.py).  Fixed-point sum: table
                 // values are integers (2^-k units, exact adds in any order); a flagged cell's slot holds the row's marker.
-                unsigned long long acc = 0ull;
-                LD_BM_BATCH_ASM(acc, Rs, Rz, Ry, Rx, lz2, lxy, kCube);
-                const long long sum = (long long)acc;
-                const long long mark = (sum + (1ll << (kBmMarkerShift - 1))) >> kBmMarkerShift;   // |true sum| < 2^49 (the scale is chosen for that)
-                const long long part = sum - (mark << kBmMarkerShift);
-                const bool one = valid && mark >= 64 && mark < 128, several = valid && mark >= 128;
+                unsigned long long acc0 = 0ull, acc1 = 0ull;   // over the pairs with receptor atoms 0 2 4 6 / 1 3 5 7 of the subtile
+                LD_BM_BATCH_ASM(acc0, acc1, Rs, Rz, Ry, Rx, lz2, lxy, kCube);
+                // each sum = marker bits + the true sum, |true sum| < 2^50 (32 pairs; the scale is chosen for that)
+                const long long sum0 = (long long)acc0, sum1 = (long long)acc1;
+                const long long mark0 = (sum0 + (1ll << (kBmMarkerShift - 1))) >> kBmMarkerShift, mark1 = (sum1 + (1ll << (kBmMarkerShift - 1))) >> kBmMarkerShift;
+                const long long part = (sum0 - (mark0 << kBmMarkerShift)) + (sum1 - (mark1 << kBmMarkerShift));
+                const long long mark = mark0 | mark1;   // (one of them 0: the other's value)
+                const bool any_flagged = valid && mark != 0;
+                const bool one = any_flagged && (mark0 == 0 || mark1 == 0) && mark >= 64 && mark < 128, several = any_flagged && !one;
                 const unsigned long long m1 = __ballot(one), m2 = __ballot(several);
                 if (one) {   // the lane's one pair in a flagged cell (0.1 % of all pairs): the exact path
                     const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
@@ -951,8 +964,15 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 const unsigned long long dbg_tb = now();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this batch's loads (and, the first time, the block's rows) are in
                 const BatchLoads cur = next;
-                // the rows' markers, over what the copy left in their slots (they name the PAIR: not part of the table)
-                if (done == 0) *reinterpret_cast<long long *>(S.cube[wave] + lane * kBmRowBytes + kBmFlagged) = (long long)(64 + lane) << kBmMarkerShift;
+                // the rows' markers, over what the copy left in their slots (they name the PAIR: not part of the table); in a block
+                // with an atom that has an interface-flag slot also in place of bins 0 and 1: those pairs go to the exact path, which
+                // sets the flags (src/dfire.rs:339-342) and adds the value
+                if (done == 0) {
+                    long long *row = reinterpret_cast<long long *>(S.cube[wave] + lane * kBmRowBytes);
+                    const long long marker = (long long)(64 + lane) << kBmMarkerShift;
+                    row[kBmFlagged / 8] = marker;
+                    if (tracked) row[0] = row[1] = marker;
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // (in the code all waves share, and unconditional -- the block's last batch asks for its first items again -- so that the
                 // loads land in the registers the next trip reads them from: behind a branch the compiler moved them there
@@ -969,7 +989,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         }
         // The exact path, at the job's end only: no call inside the block and batch loops (the compiler keeps what lives across
         // a call site in scratch for the whole job), and the lists have room for everything one job can push.
-        if (queued_blocks >= 64u) {
+        if (queued_blocks >= 64u && LD_BM_EXPERIMENT != 1) {
             const unsigned long long td = now();
             queued = bm_recheck(T, S.lut, queue_blocks, queued_blocks, queue, queued, lane);
             queued_blocks = 0;
@@ -986,7 +1006,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
     }
     {
         const unsigned long long td = now();
-        if (queued_blocks) queued = bm_recheck(T, S.lut, queue_blocks, queued_blocks, queue, queued, lane);
+        if (queued_blocks && LD_BM_EXPERIMENT != 1) queued = bm_recheck(T, S.lut, queue_blocks, queued_blocks, queue, queued, lane);
         if (queued) bm_exact_pairs(T, queue, queued, lane);
         if (DEBUG) dbg_t_drain += now() - td;
     }

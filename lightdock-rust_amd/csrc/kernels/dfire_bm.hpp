@@ -49,20 +49,21 @@ constexpr int kBmCutCell = 900 * kBmCells;   // the cutoff 4 d2 = 900
 constexpr int kBmLutBytes = 14592;           // cells 0 .. 14591: everything beyond kBmCutCell + eps reads "miss"
 constexpr float kBmCellMax = 14591.0f;
 constexpr int kBmCellZero = 14583;            // the cell of 64 d2 = 0: E = kBmCellZero + 1/2 - 64 d2 stays inside the LUT for any error below 8 cells
-// A table row T[type_i][type_j][.] as the pair kernel reads it: 20 slots of 64-bit FIXED POINT (value * fix_scale, rounded
+// A table row T[type_i][type_j][.] as the pair kernel reads it: 22 slots of 64-bit FIXED POINT (value * fix_scale, rounded
 // once on the host: integer adds are exact in any order, so a pose's sum does not depend on how the launch was cut up):
-// slots 0..17 = bins 2..19, slot 18 = 0 ("miss": beyond the cutoff, or a bin that is zero for the whole complex), slot 19 = the
-// MARKER a flagged cell reads (the cell holds a bin step, the cutoff -- hence also the reference's read past the row at
-// r = 15.0, src/dfire.rs:338 -- or pairs of bins 0 / 1, i.e. r < 2.5 A, the only ones that can set interface flags).  The LUT
-// code of a cell is the byte offset of its slot.  The marker of the block's row (i, j) is (64 + i * 8 + j) << 50, written into
-// the LDS copy of the row: a lane's 64 adds of a block leave marker bits + sum, and the marker bits say "no flagged pair",
-// WHICH pair, or "several" (dfire_bm.hip, the exact path) -- detection costs the pair loop nothing.
-constexpr int kBmRowSlots = 20;
+// slots 0..19 = bins 0..19, slot 20 = 0 ("miss": beyond the cutoff, or a bin that is zero for the whole complex), slot 21 = the
+// MARKER a flagged cell reads (the cell holds a bin step or the cutoff -- hence also the reference's read past the row at
+// r = 15.0, src/dfire.rs:338).  The LUT code of a cell is the byte offset of its slot.  The marker of the block's row (i, j) is
+// (64 + i * 8 + j) << 51, written into the LDS copy of the row: a lane's 64 adds of a block leave marker bits + sum, and the
+// marker bits say "no flagged pair", WHICH pair, or "several" (dfire_bm.hip, the exact path) -- detection costs the pair
+// loop nothing.  In a block that holds an atom with an interface-flag slot the LDS copy also carries the marker in the slots
+// of bins 0 and 1 (r < 2.5 A: the only pairs that can set interface flags, src/dfire.rs:339): the exact path sets them.
+constexpr int kBmRowSlots = 22;
 constexpr int kBmRowBytes = kBmRowSlots * 8;
-constexpr uint32_t kBmMissCode = 8 * 18;     // 144
-constexpr uint32_t kBmFlagged = 8 * 19;      // 152
-constexpr int kBmMarkerShift = 50;           // 64 sums below 2^49 under it, 64 markers of at most 127 above it: 63 bits
-__host__ __device__ inline uint32_t bm_code_of_bin(uint32_t bin) { return 8 * (bin - 2); }   // bins 2..19 -> 0..136
+constexpr uint32_t kBmMissCode = 8 * 20;     // 160
+constexpr uint32_t kBmFlagged = 8 * 21;      // 168
+__host__ __device__ inline uint32_t bm_code_of_bin(uint32_t bin) { return 8 * bin; }   // bins 0..19 -> 0..152
+constexpr int kBmMarkerShift = 51;           // a lane keeps two sums of 32 pairs each: below 2^50 under it, 32 markers of at most 127 above it: 63 bits
 constexpr int kBmJobRows = 8;                // a job = (tile pair, part of its entries, ligand subtile a): the blocks (a, 0..7); one partial sum per (entry, a)
 constexpr int kBmPartEntries = 1024;         // entries of a tile pair in one job
 constexpr int kBmCubeRows = 64;              // table rows of a block: 8 ligand x 8 receptor atoms
@@ -74,8 +75,8 @@ constexpr int kBmWavesPerCu = kBmWaves * kBmGroupsPerCu;
 constexpr int kBmQueuePairs = 8 * kBmPartEntries + 4096 + 512;   // per wave (global memory): 64-bit items, flagged pairs waiting for the exact path: what
                                              // a job can push (one per item), what it may start with, a round of bm_recheck ...
 constexpr int kBmQueueCap = kBmQueuePairs + 8 * kBmPartEntries + 64;   // ... and behind them (entry, block) items whose flagged pairs have to be found again
-constexpr double kBmFixLimit = 2097152.0;    // |table value| the fixed-point sums take (2^21); the scale is 2^(42 - e), 2^e >= the table's largest |value|:
-                                             // the 64 pairs of a block stay below 2^48, the 512 of an (entry, ligand subtile) partial below 2^51
+constexpr double kBmFixLimit = 2097152.0;    // |table value| the fixed-point sums take (2^21); the scale is 2^(44 - e), 2^e >= the table's largest |value|:
+                                             // 32 pairs of a block stay below 2^49, the 512 of an (entry, ligand subtile) partial below 2^53
 constexpr int kBmCounters = 8;               // words behind tp_count, zeroed per launch: (tile pair, part) pairs listed, jobs drawn, entries per
                                              // part, jobs listed; behind them kBmCullQueueWords item counters of dfire_bm_cull
 constexpr int kBmCullQueueWords = 256;
@@ -104,6 +105,8 @@ struct BmModel {
     double fix_scale = 0.0;                     // fixed-point units per unit of the potential
     const uint8_t *lut = nullptr;               // kBmLutBytes codes, cell' = floor(kBmCellZero + 1/2 - 64 d2)
     const uint8_t *lut_full = nullptr;          // the same without elided zero bins (counting launches)
+    const uint8_t *rec_sub_tracked = nullptr;   // [rec subtiles]: 1 = holds an atom with a flag slot
+    const uint8_t *lig_sub_tracked = nullptr;   // [lig subtiles]
     const double *table = nullptr;              // 2 x 2 x 4 patches (dfire_tiled.hpp): the exact path's table
     const double *bin_step = nullptr;
     double iface_scaled = 0.0;                  // 4 * iface_d2

@@ -661,11 +661,11 @@ double dfire_bm_error_bound(double ubound, double lig_extent) {
 // reaches (E < 0) reading cell' 0; the cells above kBmCellZero are what an error of up to 8 cells can turn a distance near 0
 // into.  Cell' k' = kBmCellZero - k holds the pairs with 64 d2 within (k - 1/2 - eps, k + 1/2 + eps),
 // i.e. a true 4 d2 within ((k - 1/2 - eps) / 16, (k + 1/2 + eps) / 16).  A cell with ONE answer for that whole interval
-// carries the byte offset of the bin's slot in the block's table rows (bm_code_of_bin(bin) = 8 (bin - 2) for bins 2..19;
+// carries the byte offset of the bin's slot in the block's table rows (bm_code_of_bin(bin) = 8 bin for bins 0..19;
 // kBmMissCode = "miss" beyond the cutoff or a bin that is zero for the whole complex); a cell with a bin step or the cutoff
-// inside is flagged (kBmFlagged, the slot of the marker): the pair is recomputed in f64.  So is every cell that can hold a
-// pair of bins 0 or 1 (r < 2.5 A): those are the only pairs that can set interface flags (the interface distance,
-// src/dfire.rs:339, lies inside bin 1), which is the exact path's business, and they are few.
+// inside is flagged (kBmFlagged, the slot of the marker): the pair is recomputed in f64.  The interface distance
+// (src/dfire.rs:339) lies inside bin 1: in a block with tracked atoms the kernel puts the marker into the slots of bins 0 and 1
+// too (dfire_bm.hpp), so every pair that can set an interface flag reaches the exact path.
 std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins) {
     const DfireBinning b = build_dfire_binning();
     const double iface_scaled = 4.0 * dfire_interface_d2();
@@ -683,13 +683,14 @@ std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins) {
             if (at < ilo) base_bin = s;
             else if (at <= ihi) flagged = true;
         }
-        if (flagged || base_bin < 2 || base_bin > 19) {
+        if (flagged || base_bin > 19) {
             code = (uint8_t)kBmFlagged;
             continue;
         }
         if (dfire_bin_reference(std::max(ilo, 0.0) / 4.0) != base_bin || dfire_bin_reference(ihi / 4.0) != base_bin)
             throw Error(LD_ERR_INVALID, "DFIRE block-major LUT self-check failed in cell " + std::to_string(k));
-        code = ((zero_bins >> base_bin) & 1u) ? (uint8_t)kBmMissCode : (uint8_t)bm_code_of_bin((uint32_t)base_bin);
+        // (bins 0 and 1 are never elided: a block with tracked atoms recognises its flag-setting pairs by their slots)
+        code = base_bin >= 2 && ((zero_bins >> base_bin) & 1u) ? (uint8_t)kBmMissCode : (uint8_t)bm_code_of_bin((uint32_t)base_bin);
     }
     if (codes[0] != kBmMissCode) throw Error(LD_ERR_INVALID, "DFIRE block-major LUT: the far cell is not a miss");
     return codes;
@@ -758,6 +759,16 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     }
     M.lut = arena_.upload(build_bm_lut(eps, packed_zero_bins_));
     M.lut_full = packed_zero_bins_ ? arena_.upload(build_bm_lut(eps, 0)) : M.lut;  // counting launches count every pair
+    {   // subtiles that hold an atom with an interface-flag slot (restraint atoms, membrane beads)
+        auto tracked = [](const TiledSoA &m) {
+            std::vector<uint8_t> t(m.hslot.size() / 8, 0);
+            for (size_t i = 0; i < m.hslot.size(); i++)
+                if (m.hslot[i] >= 0) t[i / 8] = 1;
+            return t;
+        };
+        M.rec_sub_tracked = arena_.upload(tracked(rec));
+        M.lig_sub_tracked = arena_.upload(tracked(lig));
+    }
     {   // receptor image in this frame, by the kernel that builds the packed kernel's
         const size_t pad = (size_t)rec.n_tiles * 64;
         PackedRecPair *pairs = static_cast<PackedRecPair *>(arena_.alloc_bytes(pad / 2 * sizeof(PackedRecPair)));
@@ -821,20 +832,20 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
         }
         M.lig_tile_sphere = arena_.upload(sphere);
     }
-    {   // rows[l][r][b - 2] = potential[r * 3380 + l * 20 + b] in fixed point, b = 2..19; slot 18 = 0, slot 19: the kernel's marker
+    {   // rows[l][r][b] = potential[r * 3380 + l * 20 + b] in fixed point, b = 0..19; slot 20 = 0, slot 21: the kernel's marker
         double vmax = 1.0;
         for (size_t i = 0; i < LD_DFIRE_TABLE_LEN; i++) vmax = std::max(vmax, std::fabs(desc.potential[i]));
         int e = 0;
         while (std::ldexp(1.0, e) < vmax) e++;
-        M.fix_scale = std::ldexp(1.0, 42 - e);   // the 64 pairs of a block stay below 2^48: under the markers (dfire_bm.hpp)
+        M.fix_scale = std::ldexp(1.0, 44 - e);   // 32 pairs of a block stay below 2^49: under the markers (dfire_bm.hpp)
         std::vector<long long> rows((size_t)kBmTypes * kBmTypes * kBmRowSlots, 0), ones(rows.size(), 0);
         for (uint32_t l = 0; l < (uint32_t)kBmTypes; l++)
             for (uint32_t r = 0; r < (uint32_t)kBmTypes; r++) {
                 long long *row = &rows[((size_t)l * kBmTypes + r) * kBmRowSlots], *one = &ones[((size_t)l * kBmTypes + r) * kBmRowSlots];
                 if (l >= 169 || r >= 169) continue;   // the all-zero type of padding atoms
-                for (uint32_t b = 2; b <= 19; b++) {
-                    row[b - 2] = std::llrint(desc.potential[(size_t)r * kDfireRowStride + l * 20 + b] * M.fix_scale);
-                    one[b - 2] = 1;
+                for (uint32_t b = 0; b <= 19; b++) {
+                    row[b] = std::llrint(desc.potential[(size_t)r * kDfireRowStride + l * 20 + b] * M.fix_scale);
+                    one[b] = 1;
                 }
             }
         M.rows = arena_.upload(rows);
