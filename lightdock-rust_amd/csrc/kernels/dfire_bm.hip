@@ -828,7 +828,8 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         const bool lig_tracked = T->m.lig_sub_tracked[ls] != 0;
         const uint32_t my_tracked = T->m.rec_sub_tracked[RT * 8 + (lane & 7)];
         const uint32_t lig_rowbase = T->m.lig_rowbase[ls * 8 + (lane & 7)];
-        const size_t row_base = (tp * kBmJobRows + (size_t)a) * T->cap + lo;
+        const size_t row_base = (tp * kBmJobRows + (size_t)a) * T->cap + lo;   // ([tile pair][row][entry]: the batch's lanes write next to each other; with an entry's 8 sums
+                                                                              // together, for the gather's sake, the pair kernel took 200 us longer)
         const size_t row_base_entry = tp * T->cap + lo;
         if (DEBUG) dbg_t_scan += now() - dbg_tj;   // job set-up
         for (int b = 0; b < 8; b++) {
@@ -838,10 +839,12 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous block's reads are done
                 const int dma_row = lane / kRowPieces;                          // (constants of the lane)
                 const uint32_t dma_piece = (uint32_t)(lane % kRowPieces) * 16u;
+                // lane r: where row r = (i, j) = (r / 8, r % 8) of the block starts in the table
+                const uint32_t row_src = (uint32_t)__shfl((int)lig_rowbase, lane >> 3, 64) + (uint32_t)__shfl((int)roff_all, b * 8 + (lane & 7), 64);
 #pragma unroll
                 for (int t = 0; t < kDma; t++) {
-                    const int row = t * kDmaRows + dma_row;   // (i, j) = (row / 8, row % 8)
-                    const uint32_t src = (uint32_t)__shfl((int)lig_rowbase, (row >> 3) & 7, 64) + (uint32_t)__shfl((int)roff_all, b * 8 + (row & 7), 64) + dma_piece;
+                    const int row = t * kDmaRows + dma_row;
+                    const uint32_t src = (uint32_t)__shfl((int)row_src, row & 63, 64) + dma_piece;
                     if (lane < kDmaRows * kRowPieces && row < kBmCubeRows)
                         __builtin_amdgcn_global_load_lds((const global_u32 *)(table_rows + src), (lds_u32 *)(S.cube[wave] + t * (kDmaRows * kBmRowBytes)), 16, 0, 0);
                 }
@@ -867,6 +870,29 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                     n_items += (uint32_t)__popcll(m);
                 }
             }
+            // what a lane of a batch needs from memory, loaded one batch ahead: the pose's affine map out of the [row][12] table
+            // (L2: the pass's table is 48 bytes a pose) and the entry's partial sum so far
+            struct BatchLoads {
+                float4 a0, a1, a2;   // the entry's affine map
+                long long prev;      // the entry's partial of this row so far
+                uint32_t item;
+            };
+            auto issue_loads = [&](uint32_t first_item) {
+                BatchLoads L;
+                const uint32_t at = first_item + (uint32_t)lane;
+                L.item = WS.items[at < n_items ? at : first_item];
+                const uint32_t el = L.item & 0x7fffu;
+                const float4 *ap = reinterpret_cast<const float4 *>(T->rt) + (size_t)WS.rows[el] * 3;
+                L.a0 = ap[0];
+                L.a1 = ap[1];
+                L.a2 = ap[2];
+                L.prev = 0;
+                if (!(L.item & 0x8000u)) L.prev = T->ent_partial[row_base + el];
+                return L;
+            };
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the item list as every lane wrote it
+            BatchLoads next = issue_loads(0);
+            // (behind the first batch's loads: their latency covers it)
             // receptor subtile b of the tile: 4 pair records, wave-uniform, out of the registers loaded at the job's start
             // The block's distance arithmetic has its origin at the centre c of the receptor subtile's box:
             //   E = seed - |l - r|^2 = (seed - |r - c|^2) - |l - c|^2 + 2 (r - c) . (l - c),     cell' = (u32)E
@@ -891,28 +917,6 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 Ry[q] = y * v2f{2.f, 2.f};
                 Rz[q] = z * v2f{2.f, 2.f};
             }
-            // what a lane of a batch needs from memory, loaded one batch ahead: the pose's affine map out of the [row][12] table
-            // (L2: the pass's table is 48 bytes a pose) and the entry's partial sum so far
-            struct BatchLoads {
-                float4 a0, a1, a2;   // the entry's affine map
-                long long prev;      // the entry's partial of this row so far
-                uint32_t item;
-            };
-            auto issue_loads = [&](uint32_t first_item) {
-                BatchLoads L;
-                const uint32_t at = first_item + (uint32_t)lane;
-                L.item = WS.items[at < n_items ? at : first_item];
-                const uint32_t el = L.item & 0x7fffu;
-                const float4 *ap = reinterpret_cast<const float4 *>(T->rt) + (size_t)WS.rows[el] * 3;
-                L.a0 = ap[0];
-                L.a1 = ap[1];
-                L.a2 = ap[2];
-                L.prev = 0;
-                if (!(L.item & 0x8000u)) L.prev = T->ent_partial[row_base + el];
-                return L;
-            };
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the item list as every lane wrote it
-            BatchLoads next = issue_loads(0);
             if (DEBUG) dbg_t_block += now() - dbg_tblk;   // block set-up
 
             // ---- one batch: lane = entry.  WAVE = this wave's number in the workgroup, a constant of the code.
@@ -1069,10 +1073,12 @@ __global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arg
                     part[k][jrow] = on ? T->ent_partial[at + (size_t)jrow * T->cap] : 0ll;
                 }
             }
+            long long group = 0;   // 32 partial sums below 2^53 each: exact, and one conversion instead of 32 (they were 85 us of the kernel)
 #pragma unroll
             for (int k = 0; k < 4; k++)
 #pragma unroll
-                for (int jrow = 0; jrow < kBmJobRows; jrow++) s += (double)part[k][jrow];
+                for (int jrow = 0; jrow < kBmJobRows; jrow++) group += part[k][jrow];
+            s += (double)group;
         }
     }
     s_sum[tid] = s;

@@ -1,19 +1,19 @@
-# GPU box: rocprofv3 kernel trace of one bench workload for every prebuilt library variant (top kernels by time)
-# usage: bash tools/trace_variants.sh <workload>
+# GPU box: rocprofv3 --kernel-trace averages of the block-major kernels for every prebuilt library variant
+# usage: bash tools/trace_variants.sh [bench args]
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 L=lightdock-rust_amd/lib
 cp $L/liblightdock_hip.so /tmp/keep.so
 for v in $L/variants/*.so; do
   cp $v $L/liblightdock_hip.so
-  n=$(basename $v .so); out=gpurun_out/trace_$n; rm -rf $out; mkdir -p $out
-  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --workload $1 --steps 10 --warmup 3 --cpu-seconds 0 > $out/bench.json 2> $out/log
+  n=$(basename $v .so); rm -rf /tmp/tr_$n
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_$n -- python3 bench.py --steps 10 --warmup 3 --cpu-seconds 0 "$@" > /dev/null 2>&1
   echo "== $n"
-  f=$(find $out -name "*kernel_stats.csv" | head -1)
-  if [ -n "$f" ]; then python3 - "$f" <<'PY'
-import csv, sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:8]:
-    print("  %-70s calls %4s avg %10.1f us" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3))
-PY
-  fi
+  python3 - /tmp/tr_$n <<'P'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/*/*kernel_stats.csv"):
+    for r in csv.DictReader(open(f)):
+        if "dfire_bm" in r["Name"] or "finish" in r["Name"]:
+            print("   %-60s calls %3s avg %9.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
+P
 done
 cp /tmp/keep.so $L/liblightdock_hip.so
