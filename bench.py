@@ -20,15 +20,16 @@ the hot path over one batch that already lives in HBM):
   gso-1k4c        the headline system inside the GSO loop, --swarms (default 64) per rank (weak).
 
 DFIRE uses the synthetic DCparams (the real table is not in the reference mount).
-`roofline` prices the pair kernel with ALGORITHMIC bytes: DFIRE 26*(N_rec+N_lig) +
-8*P_cut + 64 per pose with P_cut counted on the GPU for the actual batch; DNA 48*(N_rec+N_lig) +
-240 per ANM-deformed atom + 64.  Kernel time from HIP events on the launch stream.  The working set
-lives in L2, so the HBM fraction is a bookkeeping figure; `roofline.compute` is the second view the
-survey asks for: vector instructions actually issued (rocprofv3 SQ_INSTS_VALU of this command,
-profiles/) against the chip's issue rate, and the pair tests actually evaluated (not the nominal
-N_rec x N_lig).  `cpu_baseline` times the CPU oracle (oracle/, a loop-for-loop C port of the Rust
-reference, which cannot be built here) on this box's host cores, pthreads inside the library, over
-a bounded sample of the same poses.
+`roofline` reports what BINDS the pair kernel: these kernels are lookup / reduction loops whose table reads never leave
+the CU (LDS) or the L2, so the headline roof is the vector issue rate -- wave-level vector instructions of a launch
+(rocprofv3 SQ_INSTS_VALU of this same command, committed under profiles/ and tied to the kernel sources by a hash) times
+the 4.5 cycles most of them take on gfx950, over the kernel time measured live with HIP events on the launch stream --
+with the LDS pipe's busy share beside it (`roofline.lds`).  `roofline.hbm_model` keeps SURVEY 8d's byte model
+(DFIRE 26*(N_rec+N_lig) + 8*P_cut + 64 per pose with P_cut counted on the GPU for the actual batch; DNA
+48*(N_rec+N_lig) + 240 per ANM-deformed atom + 64) against the 8 TB/s HBM roof: a bookkeeping figure, because the
+8*P_cut table bytes are served from LDS; it is flagged `model_exceeded` when it passes 1.  `roofline.traffic` is the HBM
+traffic the counters saw.  `cpu_baseline` times the CPU oracle (oracle/, a loop-for-loop C port of the Rust reference,
+which cannot be built here) on this box's host cores, pthreads inside the library, over a bounded sample of the same poses.
 """
 import argparse
 import json
@@ -199,10 +200,33 @@ def spawn_ranks(n, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    codes = [p.wait() for p in procs]
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        raise SystemExit("rank(s) failed: %s" % ", ".join("%d (exit %d)" % rc for rc in bad))
+    # Poll: when one rank dies the others would sit in their rendezvous or a collective until the backend's timeout
+    # (10 to 30 minutes) -- end them and report.
+    import time as _time
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            deadline = _time.time() + 5.0          # the others may be failing for the same reason: let them say so
+            while _time.time() < deadline and any(p.poll() is None for p in procs):
+                _time.sleep(0.05)
+            ended = []
+            for r, p in enumerate(procs):
+                if p.poll() is None:
+                    p.terminate()
+                    try:
+                        p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        p.wait()
+                    ended.append(r)
+            failed = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0 and r not in ended]
+            raise SystemExit("rank(s) failed: %s%s" % (", ".join("%d (exit %d)" % rc for rc in failed),
+                                                       "; ended rank(s) %s that were still waiting" % ended if ended else ""))
+        _time.sleep(0.05)
     raise SystemExit(0)
 
 
@@ -219,6 +243,9 @@ def main():
                     help="DFIRE: zero bin 19 (14..15 A) of the synthetic table, as DFIRE's reference state does by construction; "
                          "NOT the headline configuration, reported separately in DESIGN.md")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--no-stats", action="store_true",
+                    help="skip the counting launch (in-cutoff pairs, blocks) in front of the timed region: for profiler runs, whose per-kernel "
+                         "means then cover one population of launches; the byte model is not reported")
     args = ap.parse_args()
     system, kind, default_size = WORKLOADS[args.workload]
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -278,14 +305,18 @@ def main():
             scorer.energy_batch_device(batch, d_poses.data_ptr(), poses.shape[1], d_out.data_ptr(), None,
                                        d_cnt.data_ptr() if counts else None)
 
-        # pairs inside the outer cutoff of this batch (counting variant of the kernel, outside the timed region)
-        step(counts=True)
-        torch.cuda.synchronize()
-        p_cut = d_cnt.cpu().numpy().astype(np.int64)
-        try:
-            blocks = float(scorer.last_block_counts(batch).mean())     # 8x8 blocks the box culling let through
-        except pkg.LightdockError:
-            blocks = None
+        # pairs inside the outer cutoff of this batch (a counting launch, outside the timed region)
+        blocks = None
+        if args.no_stats:
+            p_cut = np.zeros(batch, dtype=np.int64)
+        else:
+            step(counts=True)
+            torch.cuda.synchronize()
+            p_cut = d_cnt.cpu().numpy().astype(np.int64)
+            try:
+                blocks = float(scorer.last_block_counts(batch).mean())     # 8x8 blocks the box culling let through
+            except pkg.LightdockError:
+                blocks = None
         gather_bytes = 8 * int(p_cut.sum()) if case["method"] == "dfire" else 0
         algo_bytes_launch = float(info["stream_bytes_per_pose"] * batch + gather_bytes)
         for _ in range(args.warmup):
@@ -402,25 +433,42 @@ def main():
                   "random_line_gather_ceiling": L2_GATHER_CEILING_GBS, "frac_of_gather_ceiling": rate / L2_GATHER_CEILING_GBS,
                   "source": "TCP_TCC_READ_REQ_sum per launch of the pair kernel (profiles/), 128 bytes each; ceiling measured by "
                             "tools/microbench/l2_gather.hip (profiles/r02_l2_gather_ceiling.txt)"}
+        hbm_frac = achieved / HBM_PEAK_GBS
+        hbm_model = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac,
+                     "model_exceeded": bool(hbm_frac > 1.0), "algorithmic_bytes_per_launch": algo_bytes_launch,
+                     "note": "SURVEY 8d's byte model over the kernel time: 8 bytes per in-cutoff pair are table reads that the block-major "
+                             "kernels serve from LDS (the pose-major ones from L2), so this is bookkeeping, not HBM utilisation; the "
+                             "measured HBM traffic is `traffic`"}
+        if args.no_stats and kind == "k1":
+            hbm_model = None      # (no counting launch ran: P_cut unknown)
+        lds = None
+        if prof.get("lds_busy_cycles_per_launch"):
+            busy = prof["lds_busy_cycles_per_launch"] / (256 * 2.4e9 * kern_s)
+            lds = {"bound": "LDS pipe busy (SQ_LDS_IDX_ACTIVE per CU)", "frac": busy, "bank_conflict_share": prof.get("lds_bank_conflict_share"),
+                   "note": "of the whole sequence's time; the pair kernel alone keeps it busier"}
+        if binding:      # what binds: vector issue
+            roof = {"bound": "valu-issue", "achieved": prof["valu_insts_per_launch"] / kern_s / 1e9, "peak": 1024 * 2.4 / 4.5,
+                    "unit": "G wave-instructions/s", "frac": binding["frac_of_kernel_time"]}
+        else:            # no counter profile of this build: the byte model, flagged as such
+            roof = {"bound": "hbm", "achieved": achieved if hbm_model else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": hbm_frac if hbm_model else None, "model_exceeded": bool(hbm_frac > 1.0)}
+        roof.update({"traffic": prof.get("hbm_bytes_per_launch"), "kernel": info["pair_kernel_name"], "kernel_ms": 1e3 * kern_s,
+                     "note": ("`kernel_ms` brackets the whole block-major sequence (memset, dfire_bm_pose, _cull, _plan, _census, _order, _pairs, "
+                              "_gather) and `traffic`, `compute`, `binding`, `lds` are sums over it; vector instructions from the committed "
+                              "rocprofv3 pass of this command (profiles/), most of them 4.5 cycles per wave on a SIMD; "
+                              "without a profile of this build (`profile_stale`) the byte model stands in") if info["pair_kernel_name"].startswith("dfire_bm") else
+                             ("vector instructions from the committed rocprofv3 pass of this command (profiles/) at 4.5 cycles per wave on a SIMD, over "
+                              "the live kernel time; the working set is L2 resident -- see also `l2`, `l1`"),
+                     "profile_stale": stale, "hbm_model": hbm_model, "binding": binding, "compute": compute, "lds": lds, "l1": l1, "l2": l2,
+                     "nominal_pair_tests_per_s": info["pair_tests_per_pose"] * units_per_launch / kern_s,
+                     "evaluated_pair_tests_per_s": (64.0 * blocks * units_per_launch / kern_s) if blocks else None})
         out = {
             "metric": "pose-energy evals/sec (%s, %s)" % (case["method"].upper(), args.workload),
             "value": total_evals / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": dict({"workload": shape, "parallelism": "swarm-sharded x%d, no collectives" % world}, **extra),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": prof.get("hbm_bytes_per_launch"),
-                         "kernel": info["pair_kernel_name"], "kernel_ms": 1e3 * kern_s,
-                         "algorithmic_bytes_per_launch": algo_bytes_launch,
-                         "note": ("algorithmic bytes (SURVEY 8d) over kernel time; `kernel_ms` brackets the whole block-major sequence "
-                                  "(memset, dfire_bm_pose, _cull, _plan, _census, _order, _pairs, _gather) and `traffic`, `compute`, `binding` "
-                                  "are sums over it; the pair kernel stages table rows in LDS, so its HBM traffic is the entries' affine "
-                                  "maps and partial sums, not the table") if info["pair_kernel_name"].startswith("dfire_bm") else
-                                 ("algorithmic bytes (SURVEY 8d) over kernel time; the working set is L2 resident, so measured HBM "
-                                  "traffic (`traffic`) is far below it and the binding limits are on chip -- see `l2`, `l1`, `compute`"),
-                         "profile_stale": stale, "binding": binding, "compute": compute, "l1": l1, "l2": l2,
-                         "nominal_pair_tests_per_s": info["pair_tests_per_pose"] * units_per_launch / kern_s,
-                         "evaluated_pair_tests_per_s": (64.0 * blocks * units_per_launch / kern_s) if blocks else None},
+            "roofline": roof,
         }
         if args.cpu_seconds > 0 and world == 1:      # reported baseline: rank 0 at N = 1 only
             visible, quota = host_cores()
@@ -432,9 +480,10 @@ def main():
             cb["cgroup_cpu_quota"] = quota       # None = unlimited; `cores` = the threads run = min(visible, 64, quota)
             out["cpu_baseline"] = cb
             n = min(len(cpu_e), len(energies))
-            rel = float(np.max(np.abs(energies[:n] - cpu_e[:n]) / np.maximum(np.abs(cpu_e[:n]), 1e-9)))
+            # relative, absolute below 1: the DFIRE sums are fixed point (2^-40 of the synthetic table's units), an absolute error model
+            rel = float(np.max(np.abs(energies[:n] - cpu_e[:n]) / np.maximum(np.abs(cpu_e[:n]), 1.0)))
             out["parity_max_rel_err_vs_cpu_sample"] = rel
-            if rel > 1e-9:                           # north_star's tolerance
+            if rel > 1e-9:                           # (north_star's tolerance is 1e-4)
                 raise SystemExit("parity violated: %g" % rel)
         print(json.dumps(out))
     if dist is not None:

@@ -853,6 +853,7 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     }
     // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x (12 + 8 per job row + 8 in the gather list) bytes
     const size_t tile_pairs = (size_t)rec.n_tiles * lig.n_tiles;
+    if (tile_pairs * kBmPartEntries * (20 + 8 * kBmJobRows) > ((size_t)16 << 30)) return;   // even the smallest pass (1024 poses) would not fit 16 GiB: the pose-major kernels
     size_t chunk = ((size_t)4 << 30) / ((20 + 8 * kBmJobRows) * tile_pairs);   // a second such workspace exists while two passes are in flight
     chunk = std::min<size_t>(kBmMaxPassPoses, std::max<size_t>(kBmPartEntries, chunk / kBmPartEntries * kBmPartEntries));
     if (const char *e = std::getenv("LIGHTDOCK_BM_CHUNK")) {

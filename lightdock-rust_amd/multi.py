@@ -20,10 +20,11 @@ def world(dist):
 
 
 def device_of_rank(local_rank, visible_devices, forced=None):
-    """The device a rank computes on.  One process per GPU: local rank r takes device r; a rank that sees only its own
-    GPU (per-rank HIP_VISIBLE_DEVICES) takes device 0; `forced` (LD_BENCH_FORCE_DEVICE / LIGHTDOCK_FORCE_DEVICE) pins every rank to
-    one device for dry runs of the N-rank path on a 1-GPU box.  More ranks than devices without `forced` is an error:
-    silently sharing a GPU would report 1-GPU numbers as an N-GPU curve."""
+    """The device a rank computes on.  One process per GPU: local rank r takes device r; a rank whose launcher gave it its
+    own GPU (per-rank HIP_VISIBLE_DEVICES plus LD_RANK_OWNS_DEVICE=1, or a job of one local rank) takes device 0; `forced`
+    (LD_BENCH_FORCE_DEVICE in bench.py, LIGHTDOCK_DEVICE in launch.py) pins every rank to one device for dry runs of the
+    N-rank path on a 1-GPU box.  More ranks than devices without `forced` is an error -- also when a job-wide
+    HIP_VISIBLE_DEVICES=0 hides the others: silently sharing a GPU would report 1-GPU numbers as an N-GPU curve."""
     if forced is not None and str(forced) != "":
         d = int(forced)
         if not 0 <= d < max(1, visible_devices):
@@ -33,7 +34,7 @@ def device_of_rank(local_rank, visible_devices, forced=None):
         raise ValueError("no device visible")
     if visible_devices == 1:
         if local_rank > 0 and not _own_visible_device():
-            raise ValueError("local rank %d but one device visible and no per-rank HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES" % local_rank)
+            raise ValueError("local rank %d but one device visible and no per-rank HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES with LD_RANK_OWNS_DEVICE=1" % local_rank)
         return 0
     if local_rank >= visible_devices:
         raise ValueError("local rank %d but %d devices visible" % (local_rank, visible_devices))
@@ -41,8 +42,13 @@ def device_of_rank(local_rank, visible_devices, forced=None):
 
 
 def _own_visible_device():
+    """One visible device is this rank's OWN only if the launcher says so (LD_RANK_OWNS_DEVICE=1 next to its per-rank
+    HIP_VISIBLE_DEVICES) or the job has one local rank: a visibility variable alone may be job-wide."""
     import os
-    return any(os.environ.get(k) not in (None, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    if os.environ.get("LOCAL_WORLD_SIZE", "") == "1":
+        return True
+    masked = any(os.environ.get(k) not in (None, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    return masked and os.environ.get("LD_RANK_OWNS_DEVICE") == "1"
 
 
 def shard(n_items, rank, world_size):

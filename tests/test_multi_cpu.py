@@ -106,8 +106,16 @@ def test_rank_to_device_mapping(pkg, monkeypatch):
     assert multi.device_of_rank(3, 8, forced="5") == 5
     with pytest.raises(ValueError):
         multi.device_of_rank(0, 2, forced="2")
-    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3")        # per-rank visibility: the one device it sees is its own
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")        # a job-wide mask: still N ranks on one GPU
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    with pytest.raises(ValueError):
+        multi.device_of_rank(3, 1)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3")        # per-rank visibility, and the launcher says so: the one device it sees is its own
+    monkeypatch.setenv("LD_RANK_OWNS_DEVICE", "1")
     assert multi.device_of_rank(3, 1) == 0
+    monkeypatch.delenv("LD_RANK_OWNS_DEVICE")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")            # a job of one local rank
+    assert multi.device_of_rank(0, 1) == 0
 
 
 def test_bench_spawns_its_own_ranks(tmp_path):

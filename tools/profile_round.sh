@@ -1,15 +1,16 @@
 # Collects the rocprofv3 evidence of a round (run on the GPU box):
 #   per workload: --kernel-trace --stats of the bench command (no counters), then separate --pmc passes
-#   (gpurun refuses --pmc combined with tracing domains), then the un-profiled bench line.
+#   (gpurun refuses --pmc combined with tracing domains), then the un-profiled bench line.  The profiled runs skip bench.py's
+#   counting launch (--no-stats): every kernel of a sequence then runs the same number of times, and a mean per launch is one population.
 # Usage: bash tools/profile_round.sh <tag> [workload ...]     -> gpurun_out/prof_<tag>/<workload>/
 tag=${1:-r03}; shift
 wls=${@:-1k4c 1ppe 1azp-dna gso-1ppe gso-1k4c}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for w in $wls; do
   out=gpurun_out/prof_$tag/$w; mkdir -p $out
-  B="python3 bench.py --workload $w --steps 10 --warmup 3 --cpu-seconds 0"
+  B="python3 bench.py --workload $w --steps 10 --warmup 3 --cpu-seconds 0 --no-stats"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B > $out/bench_traced.json 2> $out/trace.log
-  P="python3 bench.py --workload $w --steps 3 --warmup 1 --cpu-seconds 0"
+  P="python3 bench.py --workload $w --steps 3 --warmup 1 --cpu-seconds 0 --no-stats"
   i=0
   while read -r set; do
     i=$((i+1))

@@ -8,7 +8,7 @@ import os
 import sys
 
 out = sys.argv[1]
-KERNELS = ("dfire_bm_pairs<false", "dfire_bm_cull<false", "dfire_bm_gather<false", "dfire_bm_pose", "dfire_bm_plan", "dfire_bm_census", "dfire_bm_order",
+KERNELS = ("dfire_bm_pairs<false", "dfire_bm_cull<false", "dfire_bm_gather", "dfire_bm_pose", "dfire_bm_plan", "dfire_bm_census", "dfire_bm_order",
            "dfire_packed_pairs<false", "dfire_tiled_pairs<false", "pose_energy_pairs<1", "pose_energy_pairs<0", "gso_movement_phase",
            "pose_energy_finish", "dfire_packed_prepare")
 
@@ -30,7 +30,7 @@ def counters():
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 
 
-print("== kernel trace (rocprofv3 --kernel-trace --stats) of: bench.py --workload %s --steps 10 --warmup 3" % os.path.basename(out.rstrip("/")))
+print("== kernel trace (rocprofv3 --kernel-trace --stats) of: bench.py --workload %s --steps 10 --warmup 3 --no-stats (no counting launch: every kernel of the sequence runs 13 times)" % os.path.basename(out.rstrip("/")))
 for p in glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv")):
     for i, r in enumerate(csv.DictReader(open(p))):
         if i < 11:
@@ -57,8 +57,11 @@ for kern, c in allc.items():
         # request for wide streaming reads (MI355X_MICROARCH.md, HBM): the upper estimate doubles it.
         lo = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
         hi = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
-        print("  HBM bytes per launch: %.4g (as reported) .. %.4g (FETCH_SIZE x2 gfx950 correction)" % (lo, hi))
-        print("  traffic_json hbm_bytes_per_launch %.0f" % hi)
+        # profiles/r04_fetch_size_calibration.txt: coalesced reads are 128-byte requests counted as 64 (x 2); the random 8-byte
+        # reads of dfire_bm_gather are one request each, counted as 64 bytes: taken as reported
+        best = lo if kern.startswith("dfire_bm_gather") else hi
+        print("  HBM bytes per launch: %.4g (as reported) .. %.4g (FETCH_SIZE x2 gfx950 correction); calibrated for this kernel's access pattern: %.4g" % (lo, hi, best))
+        print("  traffic_json hbm_bytes_per_launch %.0f" % best)
     if "SQ_INSTS_VALU" in c:
         print("  traffic_json valu_insts_per_launch %.0f" % c["SQ_INSTS_VALU"])
     if "SQ_ACTIVE_INST_SCA" in c and "SQ_ACTIVE_INST_VALU" in c and "SQ_WAVE_CYCLES" in c:

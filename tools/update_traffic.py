@@ -51,13 +51,16 @@ for wdir in sorted(glob.glob(os.path.join(src, "*"))):
     for key, field in (("traffic_json hbm_bytes_per_launch", "hbm_bytes_per_launch"), ("SQ_INSTS_VALU", "valu_insts_per_launch"),
                        ("SQ_INSTS_SALU", "salu_insts_per_launch"), ("SQ_INSTS_VMEM_RD", "vmem_insts_per_launch"),
                        ("TCP_TOTAL_CACHE_ACCESSES_sum", "tcp_cache_accesses_per_launch"), ("TCP_TCC_READ_REQ_sum", "l2_read_requests_per_launch"),
-                       ("FETCH_SIZE", "fetch_size_kib"), ("WRITE_SIZE", "write_size_kib"), ("SQ_INSTS_LDS", "lds_insts_per_launch")):
+                       ("FETCH_SIZE", "fetch_size_kib"), ("WRITE_SIZE", "write_size_kib"), ("SQ_INSTS_LDS", "lds_insts_per_launch"),
+                       ("SQ_LDS_IDX_ACTIVE", "lds_busy_cycles_per_launch"), ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict_cycles_per_launch")):
         v = val(key)
         if v is not None:
             entry[field] = v
     entry["valu_source"] = "SQ_INSTS_VALU (wave-level vector instructions) per launch of %s, same file" % (
         "the block-major sequence (pose, cull, plan, census, order, pairs, gather)" if kernel.startswith("dfire_bm") else kernel)
     entry["binding"] = "valu-issue"
+    if entry.get("lds_busy_cycles_per_launch"):
+        entry["lds_bank_conflict_share"] = entry.get("lds_bank_conflict_cycles_per_launch", 0.0) / entry["lds_busy_cycles_per_launch"]
     if kernel.startswith("dfire_bm"):
         entry["kernels"] = {name.split("<")[0]: float(re.search(r"^\s*SQ_INSTS_VALU\s+([0-9.e+]+)", body, re.M).group(1))
                             for name, body in secs if name.startswith("dfire_bm_") and re.search(r"^\s*SQ_INSTS_VALU", body, re.M)}
