@@ -106,6 +106,10 @@ __device__ __forceinline__ ExactCtx bm_exact_ctx(BmArgs *T, size_t pose) {
 __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
     const size_t rows = bm_rows(T);   // (a launch sized for every glowworm of a GSO costs what the glowworms that moved cost)
+    {   // the sequence's counters: entries per tile pair, jobs, the culling kernel's item counters (one memset launch less)
+        const size_t words = (size_t)T->m.lig.n_tiles * T->m.rec_n_tiles + kBmCounters + kBmCullQueueWords;
+        for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < words; k += (size_t)gridDim.x * 256) T->tp_count[k] = 0u;
+    }
     for (size_t listed = (size_t)blockIdx.x * 256 + threadIdx.x; listed < rows; listed += (size_t)gridDim.x * 256) {
         const long long p = bm_pose_of(T, listed);
         if (p < 0) continue;
@@ -384,16 +388,21 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
 // share each staging of a block's table rows); a launch with few entries -- the late steps of a GSO run, when few
 // glowworms still move -- is cut finer so that its jobs still spread over every wave of the chip.
 // ---------------------------------------------------------------------------------------------
+// entries per part of a tile pair with n entries: its ceil(n / P) parts are EQUAL (a multiple of 64 each; with parts of P and a
+// remainder, a tile pair of 1070 entries -- the average of a 1k4c launch -- was one full job and one of 46 entries that paid
+// the same set-ups for batches a quarter full)
+__device__ __forceinline__ uint32_t bm_part_size(uint32_t n, uint32_t P) {
+    const uint32_t parts = (n + P - 1) / P;
+    return parts ? ((n + parts - 1) / parts + 63u) / 64u * 64u : P;
+}
+
 __global__ __launch_bounds__(1024) void dfire_bm_plan(const BmLaunch launch_arguments) {
-    // One workgroup.  Jobs are listed longest first (by entries, in 16 classes): the persistent waves of
-    // dfire_bm_pairs draw them in that order, so the launch ends on its shortest jobs.
+    // One workgroup: P, and the list of (tile pair, part) pairs in any order (dfire_bm_order sorts the jobs).
     BmArgs *T = LD_BM_ARGS;
-    __shared__ uint32_t s_class[18];   // [c]: parts of more than (c - 1) P / 16 and at most c P / 16 entries; then cursors
-    __shared__ uint32_t s_total;
+    __shared__ uint32_t s_total, s_at;
     const int tid = threadIdx.x;
     const uint32_t n_tp = (uint32_t)(T->m.lig.n_tiles * T->m.rec_n_tiles);
-    if (tid < 18) s_class[tid] = 0;
-    if (tid == 0) s_total = 0;
+    if (tid == 0) s_total = s_at = 0;
     __syncthreads();
     uint32_t mine = 0;
     for (uint32_t tp = tid; tp < n_tp; tp += 1024) mine += T->tp_count[tp];
@@ -404,44 +413,22 @@ __global__ __launch_bounds__(1024) void dfire_bm_plan(const BmLaunch launch_argu
 #ifndef LD_BM_P_FACTOR
 #define LD_BM_P_FACTOR 4
 #endif
-    uint32_t P = (s_total * LD_BM_P_FACTOR / waves + 63u) / 64u * 64u;
+    uint32_t P = (uint32_t)(((unsigned long long)s_total * LD_BM_P_FACTOR / waves + 63u) / 64u * 64u);
     P = P < 64u ? 64u : P > (uint32_t)kBmPartEntries ? (uint32_t)kBmPartEntries : P;
-    const uint32_t step = P / 16u;
     for (uint32_t tp = tid; tp < n_tp; tp += 1024) {
         const uint32_t n = T->tp_count[tp];
         if (n == 0) continue;
-        const uint32_t full = n / P, rest = n % P;
-        if (full) atomicAdd(&s_class[16], full);
-        if (rest) atomicAdd(&s_class[(rest + step - 1) / step], 1u);
+        const uint32_t size = bm_part_size(n, P), parts = (n + size - 1) / size;
+        const uint32_t at = atomicAdd(&s_at, parts);
+        for (uint32_t k = 0; k < parts; k++) {
+            T->jobs[2 * (at + k)] = tp;
+            T->jobs[2 * (at + k) + 1] = k * size;
+        }
     }
     __syncthreads();
     if (tid == 0) {
-        uint32_t at = 0;
-        for (int c = 16; c >= 1; c--) {
-            const uint32_t k = s_class[c];
-            s_class[c] = at;
-            at += k;
-        }
-        T->job_count[0] = at;
+        T->job_count[0] = s_at;
         T->job_count[2] = P;
-    }
-    __syncthreads();
-    for (uint32_t tp = tid; tp < n_tp; tp += 1024) {
-        const uint32_t n = T->tp_count[tp];
-        if (n == 0) continue;
-        const uint32_t full = n / P, rest = n % P;
-        if (full) {
-            const uint32_t at = atomicAdd(&s_class[16], full);
-            for (uint32_t k = 0; k < full; k++) {
-                T->jobs[2 * (at + k)] = tp;
-                T->jobs[2 * (at + k) + 1] = k * P;
-            }
-        }
-        if (rest) {
-            const uint32_t at = atomicAdd(&s_class[(rest + step - 1) / step], 1u);
-            T->jobs[2 * at] = tp;
-            T->jobs[2 * at + 1] = full * P;
-        }
     }
 }
 
@@ -465,7 +452,7 @@ __global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_census(const BmLa
         const size_t tp = T->jobs[2 * jd];
         const uint32_t lo = T->jobs[2 * jd + 1];
         const uint32_t n = T->tp_count[tp];
-        const uint32_t hi = n < lo + P ? n : lo + P;
+        const uint32_t size = bm_part_size(n, P), hi = n < lo + size ? n : lo + size;
         unsigned long long m[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -555,8 +542,9 @@ __global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_order(const BmLau
 // ---------------------------------------------------------------------------------------------
 struct BmWaveShared {
     unsigned char row_bits[kBmPartEntries];        // per entry of the job: which of the 8 blocks (a, .) it holds
-    unsigned short items[kBmPartEntries + 64];     // the entries that hold the current block (| 0x8000: its first block of the row)
-    unsigned short rows[kBmPartEntries];           // per entry of the job: its row of the pass (where its affine map is)
+    unsigned short items[kBmPartEntries];          // the entries that hold the current block (| 0x8000: its first block of the row)
+    unsigned short rows[kBmPartEntries];           // per entry of the job: its row of the pass (where its affine map is), bits 0..15
+    unsigned char rows_hi[kBmPartEntries / 4];     // ... and bits 16, 17: four entries to a byte (a pass holds up to 2^18 rows)
     float4 lig_local[8];                           // the job's ligand atoms: local coordinates, w = 1 for a real atom
 };
 struct BmShared {
@@ -756,6 +744,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
     BmWaveShared &WS = S.w[wave];
     __syncthreads();
     const uint32_t n_jobs = T->job_count[3], part_entries = T->job_count[2];
+    const bool wide_rows = T->n_poses > 65536;   // (a pass of more than 2^16 rows: a GSO over hundreds of swarms)
     unsigned long long *queue = T->queue + ((size_t)blockIdx.x * kBmWaves + wave) * kBmQueueCap;   // the wave's flagged pairs
     unsigned long long *queue_blocks = queue + kBmQueuePairs;                                        // (entry, block) items with several
     uint32_t queued = 0, queued_blocks = 0;   // wave-uniform: flagged pairs listed; (entry, block) items listed
@@ -776,7 +765,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         const size_t tp = T->jobs[2 * jd];
         const uint32_t lo = T->jobs[2 * jd + 1];
         const uint32_t n = T->tp_count[tp];
-        const uint32_t hi = n < lo + part_entries ? n : lo + part_entries;
+        const uint32_t part_size = bm_part_size(n, part_entries), hi = n < lo + part_size ? n : lo + part_size;
         const int n_chunks = (int)((hi - lo + 63) / 64);
         const int lt = (int)(tp / (unsigned)n_rt), RT = (int)(tp % (unsigned)n_rt);
         const int ls = lt * 8 + a;
@@ -805,6 +794,12 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 if (k < n_chunks) {
                     WS.row_bits[k * 64 + lane] = (unsigned char)bits;
                     WS.rows[k * 64 + lane] = (unsigned short)r[k];
+                }
+                if (wide_rows) {   // the row's bits 16 and 17, four lanes to a byte
+                    uint32_t hi2 = ((r[k] >> 16) & 3u) << (2 * (lane & 3));
+                    hi2 |= (uint32_t)__shfl_xor((int)hi2, 1, 64);
+                    hi2 |= (uint32_t)__shfl_xor((int)hi2, 2, 64);
+                    if (k < n_chunks && (lane & 3) == 0) WS.rows_hi[(k * 64 + lane) >> 2] = (unsigned char)hi2;
                 }
                 any_bits |= bits;
             }
@@ -882,7 +877,9 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 const uint32_t at = first_item + (uint32_t)lane;
                 L.item = WS.items[at < n_items ? at : first_item];
                 const uint32_t el = L.item & 0x7fffu;
-                const float4 *ap = reinterpret_cast<const float4 *>(T->rt) + (size_t)WS.rows[el] * 3;
+                uint32_t row = (uint32_t)WS.rows[el];
+                if (wide_rows) row |= (((uint32_t)WS.rows_hi[el >> 2] >> (2 * (el & 3))) & 3u) << 16;
+                const float4 *ap = reinterpret_cast<const float4 *>(T->rt) + (size_t)row * 3;
                 L.a0 = ap[0];
                 L.a1 = ap[1];
                 L.a2 = ap[2];
@@ -1118,7 +1115,7 @@ hipError_t launch_bm_pose(const BmLaunch &t, hipStream_t stream) {
 
 hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    if (t.m.rec_n_tiles > 65535 || t.n_poses > kBmMaxPassPoses) return hipErrorInvalidValue;
+    if (t.m.rec_n_tiles > 1024 || t.n_poses > kBmMaxPassPoses) return hipErrorInvalidValue;
     const size_t lds = (size_t)t.m.rec_n_tiles * 9 * sizeof(TiledBox) + (size_t)kBmCullWaves * bm_cull_wave_lds(t.m.rec_n_tiles);
     // persistent workgroups (each fills its LDS with the receptor's boxes once): as many as fit the chip at this LDS size
     const size_t per_cu = std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512)));

@@ -81,7 +81,7 @@ constexpr int kBmCounters = 8;               // words behind tp_count, zeroed pe
                                              // part, jobs listed; behind them kBmCullQueueWords item counters of dfire_bm_cull
 constexpr int kBmCullQueueWords = 256;
 constexpr int kBmCostClasses = 80;           // jobs are drawn in classes of estimated length, longest first
-constexpr size_t kBmMaxPassPoses = 65536;    // a job keeps its entries' rows of the pass as 16-bit numbers
+constexpr size_t kBmMaxPassPoses = 262144;   // a job keeps its entries' rows of the pass as 18-bit numbers (LDS)
 
 struct BmModel {
     // receptor (static image in the kappa = 8 frame; no receptor ANM on this path)

@@ -944,7 +944,7 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
             t.count_mode = mode;
             t.tile_tested = mode ? static_cast<uint32_t *>(ws_bm_tile_tested_.ptr) + w * cap * n_lt : nullptr;
             t.exact_pairs = mode ? static_cast<uint32_t *>(ws_bm_exact_pairs_.ptr) + w * cap : nullptr;
-            hip_check(hipMemsetAsync(t.tp_count, 0, (tile_pairs + kBmCounters + kBmCullQueueWords) * sizeof(uint32_t), st), "hipMemsetAsync(tile pair counts)");
+            // (dfire_bm_pose zeroes the sequence's counters: tp_count and the words behind it)
             hip_check(launch_bm_pose(t, st), "launch dfire_bm_pose");
             hip_check(launch_bm_cull(t, st), "launch dfire_bm_cull");
             hip_check(launch_bm_pairs(t, st), "launch dfire_bm_pairs");
