@@ -49,7 +49,10 @@ __host__ __device__ inline int bm_gather_span(int n_lt) {
 }
 __host__ __device__ inline int bm_gather_chunks(int n_lt, int n_rt) {
     int chunks = 1;
-    while (chunks * 4 < n_rt && bm_gather_span(n_lt) * chunks * 2 <= 64) chunks <<= 1;
+#ifndef LD_BM_GATHER_THREADS
+#define LD_BM_GATHER_THREADS 64
+#endif
+    while (chunks * 4 < n_rt && bm_gather_span(n_lt) * chunks * 2 <= LD_BM_GATHER_THREADS) chunks <<= 1;
     return chunks;
 }
 constexpr float kBmBoxCut = 14400.0f * 1.00005f;  // (8 * 15 A)^2 in record units, padded for the rounding of the box test
