@@ -41,20 +41,6 @@ constexpr int kBmCullQueues = kBmCullQueueWords;   // (1k4c: 8 queues 695 us, 16
 constexpr int kBmCullHitTiles = 4;              // hit list of a dfire_bm_cull wave: room for this many poses that reach every receptor tile
 __host__ __device__ inline int bm_cull_hit_cap(int n_rt) { return kBmCullHitTiles * n_rt > 192 ? kBmCullHitTiles * n_rt : 192; }   // (a flush costs one atomic per tile pair)
 __host__ __device__ inline size_t bm_cull_wave_lds(int n_rt) { return ((size_t)bm_cull_hit_cap(n_rt) * 14 + (size_t)n_rt * 8 + 15) / 16 * 16; }
-// dfire_bm_gather: threads per pose = span (a power of two covering the ligand's tiles) x chunks (up to 64 threads per pose)
-__host__ __device__ inline int bm_gather_span(int n_lt) {
-    int span = 1;
-    while (span < n_lt && span < 512) span <<= 1;
-    return span;
-}
-__host__ __device__ inline int bm_gather_chunks(int n_lt, int n_rt) {
-    int chunks = 1;
-#ifndef LD_BM_GATHER_THREADS
-#define LD_BM_GATHER_THREADS 64
-#endif
-    while (chunks * 4 < n_rt && bm_gather_span(n_lt) * chunks * 2 <= LD_BM_GATHER_THREADS) chunks <<= 1;
-    return chunks;
-}
 constexpr float kBmBoxCut = 14400.0f * 1.00005f;  // (8 * 15 A)^2 in record units, padded for the rounding of the box test
 
 // row of the pass -> pose row, or -1 beyond the list of this launch / inactive
@@ -140,6 +126,7 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
             for (int k = 0; k < words; k++) f[k] = 0u;
         }
         if (T->exact_fix) T->exact_fix[listed] = 0;
+        for (int lt = 0; lt < T->m.lig.n_tiles; lt++) T->tile_sum[listed * (size_t)T->m.lig.n_tiles + lt] = 0;
         if (T->exact_pairs) T->exact_pairs[listed] = 0;
     }
 }
@@ -150,14 +137,6 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
 // tile: ONE atomic per tile pair for all the poses of the wave (the lists of a small complex have few heads: one
 // returning atomic per pose and tile pair serialises on them), then the entries.
 // ---------------------------------------------------------------------------------------------
-// bit a: the mask holds a block of ligand subtile a
-__device__ __forceinline__ uint32_t bm_rows_of(unsigned long long mask) {
-    uint32_t rows = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) rows |= ((mask >> (k * 8)) & 0xffull) ? 1u << k : 0u;
-    return rows;
-}
-
 template <bool COUNT>
 __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
@@ -243,7 +222,6 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     };
 
     uint32_t n_hits = 0;                 // wave-uniform: hits listed and not flushed yet
-    uint32_t my_first = 0, my_nvis = 0;  // lane g: where pose g's hits start in the list; how many it has
     // ---- the list -> entries.  One LDS atomic per hit (its place among the wave's hits of the tile pair), ONE global atomic per
     // tile pair for the whole wave (the lists of a small complex have few heads: one returning atomic per pose and tile pair
     // serialises on them), then lane = hit writes the entry: 12 bytes (the pair kernel reads the pose's affine map from the
@@ -264,8 +242,6 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
             const bool act = h < n_hits;
             const uint32_t key = act ? s_hkey[h] : 0u;
             const int g = (int)(key >> 16), RT = (int)(key & 0xffffu);
-            // what lane g holds about pose g (every lane takes part in the shuffle)
-            const uint32_t first = (uint32_t)__shfl((int)my_first, g, 64);
             if (act) {
                 const unsigned long long mask = s_hmask[h];
                 const uint32_t idx = s_base[RT] + s_hrank[h];
@@ -273,8 +249,6 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                 const uint32_t row = (uint32_t)listed0 + (uint32_t)g;
                 T->ent_row[at] = row;
                 T->ent_mask[at] = mask;
-                T->vis_entry[((size_t)row * n_lt + lt) * (size_t)n_rt + (h - first)] =
-                    (unsigned long long)RT << 48 | (unsigned long long)bm_rows_of(mask) << 32 | idx;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the list is read before it is written again
@@ -289,8 +263,6 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         if (pose_of[g] < 0) continue;
         const Affine A = affine_of(g);
         if (n_hits + (uint32_t)n_rt > (uint32_t)hit_cap) flush();
-        const uint32_t first_hit = n_hits;
-        if (lane == g) my_first = first_hit;
         // the hits of one ballot of receptor tiles, lane-distributed, written to the list together (one LDS store per lane
         // instead of a scalar branch, five register moves and two stores per hit)
         uint32_t held = 0;                  // wave-uniform
@@ -377,11 +349,9 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
             put_held();   // (a ballot's 64 receptor tiles make at most 64 hits)
         }
         if (COUNT && lane == 0) T->tile_tested[(listed0 + g) * (size_t)n_lt + lt] = tested;
-        if (lane == g) my_nvis = n_hits - first_hit;
     }
     next_ticket = draw();   // (here, not at the item's start: memory operations return in order, and the item's loads would wait for it)
     flush();
-    if (my_pose >= 0) T->vis_count[(size_t)my_row * n_lt + lt] = my_nvis;
     }
 }
 
@@ -414,7 +384,7 @@ __global__ __launch_bounds__(1024) void dfire_bm_plan(const BmLaunch launch_argu
     // about one (tile pair, part) pair per wave of the pair kernel, i.e. kBmJobRows jobs per wave
     const uint32_t waves = (uint32_t)(T->pairs_groups > 0 ? T->pairs_groups : 256) * kBmWavesPerCu;
 #ifndef LD_BM_P_FACTOR
-#define LD_BM_P_FACTOR 4
+#define LD_BM_P_FACTOR 8
 #endif
     uint32_t P = (uint32_t)(((unsigned long long)s_total * LD_BM_P_FACTOR / waves + 63u) / 64u * 64u);
     P = P < 64u ? 64u : P > (uint32_t)kBmPartEntries ? (uint32_t)kBmPartEntries : P;
@@ -739,7 +709,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
     __shared__ __attribute__((aligned(16))) BmShared S;   // the kernel's only LDS object: at LDS address 0
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_rt = T->m.rec_n_tiles;
+    const int n_rt = T->m.rec_n_tiles, n_lt = T->m.lig.n_tiles;
     {
         const uint8_t *lut = T->count_mode ? T->m.lut_full : T->m.lut;
         for (int i = tid; i < kBmLutBytes / 16; i += kBmWaves * 64) reinterpret_cast<uint4 *>(S.lut)[i] = reinterpret_cast<const uint4 *>(lut)[i];
@@ -863,7 +833,8 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                     if (act) {
                         const uint32_t at = n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                         const bool first = (bits & ((1u << b) - 1u)) == 0u;   // the entry's first block of this job: nothing to add to yet
-                        WS.items[at] = (unsigned short)((uint32_t)(k * 64 + lane) | (first ? 0x8000u : 0u));
+                        const bool last = (bits >> (b + 1)) == 0u;             // ... its last: the (entry, row)'s sum is complete
+                        WS.items[at] = (unsigned short)((uint32_t)(k * 64 + lane) | (first ? 0x8000u : 0u) | (last ? 0x4000u : 0u));
                     }
                     n_items += (uint32_t)__popcll(m);
                 }
@@ -873,15 +844,16 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
             struct BatchLoads {
                 float4 a0, a1, a2;   // the entry's affine map
                 long long prev;      // the entry's partial of this row so far
-                uint32_t item;
+                uint32_t item, row;
             };
             auto issue_loads = [&](uint32_t first_item) {
                 BatchLoads L;
                 const uint32_t at = first_item + (uint32_t)lane;
                 L.item = WS.items[at < n_items ? at : first_item];
-                const uint32_t el = L.item & 0x7fffu;
+                const uint32_t el = L.item & 0x3ffu;
                 uint32_t row = (uint32_t)WS.rows[el];
                 if (wide_rows) row |= (((uint32_t)WS.rows_hi[el >> 2] >> (2 * (el & 3))) & 3u) << 16;
+                L.row = row;
                 const float4 *ap = reinterpret_cast<const float4 *>(T->rt) + (size_t)row * 3;
                 L.a0 = ap[0];
                 L.a1 = ap[1];
@@ -925,7 +897,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 constexpr uint32_t kCube = (uint32_t)(offsetof(BmShared, cube) + (size_t)WAVE * kBmCubeBytes);   // a constant LDS address
                 const int count = n_items - done >= 64u ? 64 : (int)(n_items - done);
                 const bool valid = lane < count;   // (the lanes beyond `count` repeat the first item)
-                const uint32_t el = cur.item & 0x7fffu;
+                const uint32_t el = cur.item & 0x3ffu;
                 const Affine A{cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w - cbx, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w - cby, cur.a2.x, cur.a2.y, cur.a2.z, cur.a2.w - cbz};
                 v2f lxy[8], lz2[8];   // l - c as {x, y} and {z, |l - c|^2}: the packed operations broadcast either half (op_sel)
 #pragma unroll
@@ -961,7 +933,12 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                     }
                     queued_blocks += (uint32_t)__popcll(m2);
                 }
-                if (valid) T->ent_partial[row_base + el] = cur.prev + part;
+                // The (entry, ligand subtile)'s sum is complete with the entry's last block of the job: it goes to the pose's
+                // (row, ligand tile) sum by an integer atomic -- order-free, and no gather over 24 M scattered partial sums afterwards.
+                if (valid) {
+                    if (cur.item & 0x4000u) atomicAdd(reinterpret_cast<unsigned long long *>(T->tile_sum + (size_t)cur.row * n_lt + lt), (unsigned long long)(cur.prev + part));
+                    else T->ent_partial[row_base + el] = cur.prev + part;
+                }
             };
             for (uint32_t done = 0; done < n_items; done += 64) {
                 if (DEBUG) dbg_batches++;
@@ -1028,81 +1005,33 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
 }
 
 // ---------------------------------------------------------------------------------------------
-// dfire_bm_gather: thread = (row, ligand tile[, share of its entries]); fixed order, then a fixed tree.  The partial sums
-// are integers (fixed point); a pose's total can exceed 63 bits for an extreme table, so they are added as f64, exact up to
-// 2^53 units each, in the one order that depends on the molecules only.  A counting launch (count_mode) sums ones.
+// dfire_bm_gather: thread = row of the pass: the pose's (row, ligand tile) sums -- integers, filled by the pair kernel's
+// atomics, each below 2^61 -- added as f64 in tile order (a pose's total can pass 63 bits for an extreme table), plus the
+// exact path's sum.  A counting launch (count_mode) sums ones.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void dfire_bm_gather(const BmLaunch launch_arguments) {
+__global__ __launch_bounds__(256) void dfire_bm_gather(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
-    __shared__ double s_sum[512];
-    __shared__ uint32_t s_tested[512];
-    const int tid = threadIdx.x;
-    const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
-    const bool counting = T->count_mode != 0;
-    // thread = (row, ligand tile); a workgroup holds 512 / span rows, span = the power of two that covers the ligand's
-    // tiles.  The kernel is bound by the latency of three dependent loads per entry: many poses in flight per CU, and
-    // per thread the partial sums of four entries x all their rows requested together.
-    // A small ligand leaves threads over: `chunks` of them share a (row, ligand tile), each taking every chunks-th group of
-    // four entries (both numbers depend on the molecules only: a pose's sum is the same tree in every launch).
-    const int span_lt = bm_gather_span(n_lt), chunks = bm_gather_chunks(n_lt, n_rt), span = span_lt * chunks;
-    const int per_wg = 512 / span, sub = tid / span, r0 = tid % span;
-    const int lt0 = r0 / chunks, chunk = r0 % chunks;
+    const int n_lt = T->m.lig.n_tiles;
     const size_t n_rows = bm_rows(T);
-    for (size_t first_row = (size_t)blockIdx.x * per_wg; first_row < n_rows; first_row += (size_t)gridDim.x * per_wg) {
-    const size_t listed = first_row + sub;
-    const long long pp = listed < n_rows ? bm_pose_of(T, listed) : -1;
-    const size_t pose = pp < 0 ? 0 : (size_t)pp, row = pp < 0 ? 0 : listed;
-    double s = 0.0;
-    uint32_t tested = 0;
-    for (int lt = lt0; pp >= 0 && lt < n_lt; lt += span_lt) {   // the tile's entries in the order the culling listed them, their rows in order
-        const size_t slot = row * (size_t)n_lt + lt;
-        if (counting && T->tile_tested && chunk == 0) tested += T->tile_tested[slot];
-        const uint32_t n_vis = T->vis_count[slot];
-        for (uint32_t v0 = 4u * (uint32_t)chunk; v0 < n_vis; v0 += 4u * (uint32_t)chunks) {
-            unsigned long long ent[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) ent[k] = v0 + k < n_vis ? T->vis_entry[slot * (size_t)n_rt + v0 + k] : 0ull;
-            long long part[4][kBmJobRows];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const size_t tp = (size_t)lt * n_rt + (size_t)(ent[k] >> 48);
-                const size_t at = tp * kBmJobRows * T->cap + (size_t)(ent[k] & 0xffffffffull);
-#pragma unroll
-                for (int jrow = 0; jrow < kBmJobRows; jrow++) {
-                    const bool on = (ent[k] >> (32 + jrow)) & 1ull;   // the entry holds a block of ligand subtile jrow
-                    part[k][jrow] = on ? T->ent_partial[at + (size_t)jrow * T->cap] : 0ll;
-                }
-            }
-            long long group = 0;   // 32 partial sums below 2^53 each: exact, and one conversion instead of 32 (they were 85 us of the kernel)
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int jrow = 0; jrow < kBmJobRows; jrow++) group += part[k][jrow];
-            s += (double)group;
+    for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < n_rows; row += (size_t)gridDim.x * 256) {
+        const long long pp = bm_pose_of(T, row);
+        if (pp < 0) continue;
+        const size_t pose = (size_t)pp;
+        double units = 0.0;
+        uint32_t tested = 0;
+        for (int lt = 0; lt < n_lt; lt++) {
+            units += (double)T->tile_sum[row * (size_t)n_lt + lt];
+            if (T->count_mode && T->tile_tested) tested += T->tile_tested[row * (size_t)n_lt + lt];
         }
-    }
-    s_sum[tid] = s;
-    if (counting) s_tested[tid] = tested;
-    __syncthreads();
-    for (int half = span >> 1; half > 0; half >>= 1) {   // fixed tree, per pose
-        if (r0 < half) {
-            s_sum[tid] += s_sum[tid + half];
-            if (counting) s_tested[tid] += s_tested[tid + half];
-        }
-        __syncthreads();
-    }
-    if (r0 == 0 && pp >= 0) {
-        const double units = s_sum[tid] + (double)T->exact_fix[row];
-        if (counting) {   // (pair counts stay far below 2^53: exact)
+        units += (double)T->exact_fix[row];
+        if (T->count_mode) {   // (pair counts stay far below 2^53: exact)
             T->count_partial[pose] = (uint32_t)units;
-            if (T->tested_partial) T->tested_partial[pose] = s_tested[tid];
+            if (T->tested_partial) T->tested_partial[pose] = tested;
             if (T->exact_partial) T->exact_partial[pose] = T->exact_pairs[row];
         } else {
             T->partial[2 * pose] = units * (1.0 / T->m.fix_scale);
             T->partial[2 * pose + 1] = 0.0;
         }
-    }
-    __syncthreads();   // s_sum is reused by the next rows
     }
 }
 
@@ -1151,10 +1080,7 @@ hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
 
 hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    const int span = bm_gather_span(t.m.lig.n_tiles) * bm_gather_chunks(t.m.lig.n_tiles, t.m.rec_n_tiles);
-    const size_t per_wg = 512 / span;
-    const unsigned blocks = (unsigned)std::min<size_t>((t.n_poses + per_wg - 1) / per_wg, 16384);
-    hipLaunchKernelGGL(dfire_bm_gather, dim3(blocks), dim3(512), 0, stream, t);
+    hipLaunchKernelGGL(dfire_bm_gather, dim3((unsigned)std::min<size_t>((t.n_poses + 255) / 256, 4096)), dim3(256), 0, stream, t);
     return hipGetLastError();
 }
 

@@ -851,10 +851,10 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
         M.rows = arena_.upload(rows);
         M.rows_ones = arena_.upload(ones);
     }
-    // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x (12 + 8 per job row + 8 in the gather list) bytes
+    // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x (12 + 8 per job row) bytes
     const size_t tile_pairs = (size_t)rec.n_tiles * lig.n_tiles;
-    if (tile_pairs * kBmPartEntries * (20 + 8 * kBmJobRows) > ((size_t)16 << 30)) return;   // even the smallest pass (1024 poses) would not fit 16 GiB: the pose-major kernels
-    size_t chunk = ((size_t)4 << 30) / ((20 + 8 * kBmJobRows) * tile_pairs);   // a second such workspace exists while two passes are in flight
+    if (tile_pairs * kBmPartEntries * (12 + 8 * kBmJobRows) > ((size_t)16 << 30)) return;   // even the smallest pass (1024 poses) would not fit 16 GiB: the pose-major kernels
+    size_t chunk = ((size_t)4 << 30) / ((12 + 8 * kBmJobRows) * tile_pairs);   // a second such workspace exists while two passes are in flight
     chunk = std::min<size_t>(kBmMaxPassPoses, std::max<size_t>(kBmPartEntries, chunk / kBmPartEntries * kBmPartEntries));
     if (const char *e = std::getenv("LIGHTDOCK_BM_CHUNK")) {
         const long v = std::atol(e);
@@ -935,8 +935,7 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         t.ent_row = static_cast<uint32_t *>(ws_bm_ent_row_.ptr) + w * tile_pairs * cap;
         t.ent_mask = static_cast<unsigned long long *>(ws_bm_ent_mask_.ptr) + w * tile_pairs * cap;
         t.ent_partial = static_cast<long long *>(ws_bm_ent_partial_.ptr) + w * tile_pairs * kBmJobRows * cap;
-        t.vis_count = static_cast<uint32_t *>(ws_bm_vis_count_.ptr) + w * cap * n_lt;
-        t.vis_entry = static_cast<unsigned long long *>(ws_bm_vis_entry_.ptr) + w * cap * tile_pairs;
+        t.tile_sum = static_cast<long long *>(ws_bm_tile_sum_.ptr) + w * cap * n_lt;
         t.exact_fix = static_cast<long long *>(ws_bm_exact_fix_.ptr) + w * cap;
         // With pair counts wanted the sequence runs twice: first as a counting launch (the same kernels over rows of ones and the
         // full LUT: the sums are the in-cutoff pair counts), then for the energies.
@@ -1032,8 +1031,8 @@ Scorer::~Scorer() {
     ws_rec_tile_.release();
     ws_rec_pairs_.release();
     ws_exact_.release();
-    for (DeviceBuffer *b : {&ws_bm_rt_, &ws_bm_tp_count_, &ws_bm_ent_row_, &ws_bm_jobs_, &ws_bm_job_cost_, &ws_bm_job_order_, &ws_bm_ent_mask_, &ws_bm_queue_, &ws_bm_ent_partial_, &ws_bm_vis_count_,
-                            &ws_bm_vis_entry_, &ws_bm_tile_tested_, &ws_bm_exact_fix_, &ws_bm_exact_pairs_})
+    for (DeviceBuffer *b : {&ws_bm_rt_, &ws_bm_tp_count_, &ws_bm_ent_row_, &ws_bm_jobs_, &ws_bm_job_cost_, &ws_bm_job_order_, &ws_bm_ent_mask_, &ws_bm_queue_, &ws_bm_ent_partial_, &ws_bm_tile_sum_,
+                            &ws_bm_tile_tested_, &ws_bm_exact_fix_, &ws_bm_exact_pairs_})
         b->release();
     ws_poses_.release();
     ws_energies_.release();
@@ -1043,7 +1042,7 @@ uint64_t Scorer::workspace_generation() const {
     return ws_partial_.generation + ws_flags_.generation + ws_counts_.generation + ws_tested_.generation + ws_exact_.generation +
            ws_rec_atoms_.generation + ws_rec_sub_.generation + ws_rec_tile_.generation + ws_rec_pairs_.generation + ws_bm_rt_.generation +
            ws_bm_tp_count_.generation + ws_bm_ent_row_.generation + ws_bm_jobs_.generation + ws_bm_job_cost_.generation + ws_bm_job_order_.generation + ws_bm_ent_mask_.generation + ws_bm_queue_.generation + ws_bm_ent_partial_.generation +
-           ws_bm_vis_count_.generation + ws_bm_vis_entry_.generation + ws_bm_tile_tested_.generation +
+           ws_bm_tile_sum_.generation + ws_bm_tile_tested_.generation +
            ws_bm_exact_fix_.generation + ws_bm_exact_pairs_.generation;
 }
 
@@ -1070,8 +1069,7 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         ws_bm_ent_row_.reserve(sets * tile_pairs * cap * sizeof(uint32_t));
         ws_bm_ent_mask_.reserve(sets * tile_pairs * cap * sizeof(unsigned long long));
         ws_bm_ent_partial_.reserve(sets * tile_pairs * kBmJobRows * cap * sizeof(long long));
-        ws_bm_vis_count_.reserve(sets * cap * n_lt * sizeof(uint32_t));
-        ws_bm_vis_entry_.reserve(sets * cap * tile_pairs * sizeof(unsigned long long));
+        ws_bm_tile_sum_.reserve(sets * cap * n_lt * sizeof(long long));
         ws_bm_exact_fix_.reserve(sets * cap * sizeof(long long));
         if (counts) {
             ws_bm_tile_tested_.reserve(sets * cap * n_lt * sizeof(uint32_t));

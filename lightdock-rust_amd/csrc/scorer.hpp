@@ -157,8 +157,8 @@ class Scorer {
     hipStream_t bm_aux_stream_ = nullptr;   // the second of two passes in flight runs here
     hipEvent_t bm_fork_ = nullptr, bm_join_ = nullptr;
     int n_cus_ = 256;
-    DeviceBuffer ws_bm_debug_, ws_bm_jobs_, ws_bm_job_cost_, ws_bm_job_order_, ws_bm_rt_, ws_bm_tp_count_, ws_bm_ent_row_, ws_bm_ent_mask_, ws_bm_queue_, ws_bm_ent_partial_, ws_bm_vis_count_,
-        ws_bm_vis_entry_, ws_bm_tile_tested_, ws_bm_exact_fix_, ws_bm_exact_pairs_;
+    DeviceBuffer ws_bm_debug_, ws_bm_jobs_, ws_bm_job_cost_, ws_bm_job_order_, ws_bm_rt_, ws_bm_tp_count_, ws_bm_ent_row_, ws_bm_ent_mask_, ws_bm_queue_, ws_bm_ent_partial_, ws_bm_tile_sum_,
+        ws_bm_tile_tested_, ws_bm_exact_fix_, ws_bm_exact_pairs_;
     TiledSoA tiled_rec_soa_;          // receptor in tile order (input of dfire_prepare_receptor)
     bool rec_anm_per_pose_ = false;   // receptor ANM: one receptor image per pose per launch
     DeviceBuffer ws_rec_atoms_, ws_rec_sub_, ws_rec_tile_;

@@ -91,8 +91,7 @@ hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t) {
     if (t.n_poses) {
         t.ent_row[tile_pairs * t.cap - 1] = 0;
         t.ent_mask[tile_pairs * t.cap - 1] = 0;
-        t.vis_entry[t.n_poses * tile_pairs - 1] = 0ull;
-        t.vis_count[t.n_poses * (size_t)t.m.lig.n_tiles - 1] = 0;
+        t.tile_sum[t.n_poses * (size_t)t.m.lig.n_tiles - 1] = 0;
         t.exact_fix[t.n_poses - 1] = 0;
     }
     return hipSuccess;
