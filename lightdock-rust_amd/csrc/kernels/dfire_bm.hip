@@ -518,7 +518,7 @@ struct BmWaveShared {
     unsigned short items[kBmPartEntries];          // the entries that hold the current block (| 0x8000: its first block of the row)
     unsigned short rows[kBmPartEntries];           // per entry of the job: its row of the pass (where its affine map is), bits 0..15
     unsigned char rows_hi[kBmPartEntries / 4];     // ... and bits 16, 17: four entries to a byte (a pass holds up to 2^18 rows)
-    float4 lig_local[8];                           // the job's ligand atoms: local coordinates, w = 1 for a real atom
+    alignas(16) float lig_local[3][8];                         // the job's ligand atoms: local x of the eight, y, z (read back as pairs of atoms)
 };
 struct BmShared {
     unsigned char lut[kBmLutBytes];   // indexed from the far end: cell' = floor(kBmCellZero + 1/2 - 64 d2), everything further reads cell' 0
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         // the ligand subtile's local coordinates (uniform)
         // (kept in LDS, read back per batch as broadcasts: 24 wave-uniform values in vector registers for the whole job are what
         // pushed the block set-up into scratch)
-        if (lane < 8) WS.lig_local[lane] = reinterpret_cast<const float4 *>(T->m.lig_local)[ls * 8 + lane];
+        if (lane < 24) WS.lig_local[lane >> 3][lane & 7] = T->m.lig_local[(size_t)(ls * 8 + (lane & 7)) * 4 + (lane >> 3)];
         // table rows of a block -> LDS by LDS-DMA: an instruction copies 5 rows, lane = (row of the five, one of its 11 pieces of
         // 16 bytes) -- the lane's two numbers are the same for every instruction, 55 lanes take part (piece p of an instruction
         // lands at its LDS address + 16 p: five rows of 176 bytes, contiguous).  The lane keeps the row block of ligand atom
@@ -898,20 +898,21 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 const int count = n_items - done >= 64u ? 64 : (int)(n_items - done);
                 const bool valid = lane < count;   // (the lanes beyond `count` repeat the first item)
                 const uint32_t el = cur.item & 0x3ffu;
-                const Affine A{cur.a0.x, cur.a0.y, cur.a0.z, cur.a0.w - cbx, cur.a1.x, cur.a1.y, cur.a1.z, cur.a1.w - cby, cur.a2.x, cur.a2.y, cur.a2.z, cur.a2.w - cbz};
-                v2f lxy[8], lz2[8];   // l - c as {x, y} and {z, |l - c|^2}: the packed operations broadcast either half (op_sel)
+                // the lane's 8 ligand atoms posed two at a time (packed; the operations and their nesting are bm_apply's, so the
+                // culling kernel's boxes and the exact path see the same bits), relative to the block's centre
+                const v2f A0xy{cur.a0.x, cur.a0.y}, A0zw{cur.a0.z, cur.a0.w - cbx}, A1xy{cur.a1.x, cur.a1.y}, A1zw{cur.a1.z, cur.a1.w - cby};
+                const v2f A2xy{cur.a2.x, cur.a2.y}, A2zw{cur.a2.z, cur.a2.w - cbz};
+                v2f LX[4], LY[4], LZ[4], L2[4];   // atoms (2p, 2p + 1): l - c and |l - c|^2
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    float lx, ly, lz;
-                    const float4 L = WS.lig_local[i];
-                    bm_apply(A, L.x, L.y, L.z, lx, ly, lz);
-                    lxy[i] = v2f{lx, ly};
-                    lz2[i] = v2f{lz, __builtin_fmaf(lx, lx, __builtin_fmaf(ly, ly, lz * lz))};
+                for (int p = 0; p < 4; p++) {
+                    const v2f X = reinterpret_cast<const v2f *>(WS.lig_local[0])[p], Y = reinterpret_cast<const v2f *>(WS.lig_local[1])[p];
+                    const v2f Z = reinterpret_cast<const v2f *>(WS.lig_local[2])[p];
+                    LD_BM_POSE_ASM(LX[p], LY[p], LZ[p], L2[p], A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, X, Y, Z);
                 }
                 // The batch's 64 pairs: dfire_bm_batch.inc (generated, tools/gen_bm_batch_asm.py).  Fixed-point sum: table
                 // values are integers (2^-k units, exact adds in any order); a flagged cell's slot holds the row's marker.
                 unsigned long long acc0 = 0ull, acc1 = 0ull;   // over the pairs with receptor atoms 0 2 4 6 / 1 3 5 7 of the subtile
-                LD_BM_BATCH_ASM(acc0, acc1, Rs, Rz, Ry, Rx, lz2, lxy, kCube);
+                LD_BM_BATCH_ASM(acc0, acc1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX, kCube);
                 // each sum = marker bits + the true sum, |true sum| < 2^50 (32 pairs; the scale is chosen for that)
                 const long long sum0 = (long long)acc0, sum1 = (long long)acc1;
                 const long long mark0 = (sum0 + (1ll << (kBmMarkerShift - 1))) >> kBmMarkerShift, mark1 = (sum1 + (1ll << (kBmMarkerShift - 1))) >> kBmMarkerShift;

@@ -16,7 +16,7 @@ issues, scalar or wait, costs it a turn.
 
 Temporaries are fixed registers (clobbered): v[220:235] table values, v[236:243] / v[244:251]
 cells and codes, v[252:255] the two packed E.  Operands: acc, acc1 (+v, 64 bit: the sums over the pairs with the even / odd receptor atom of a record), Rs0..3 Rz0..3 Ry0..3 Rx0..3 (the block's receptor
-records, wave-uniform), lz0..7 = {lz, l2} and lx0..7 = {lx, ly} of the lane's ligand atoms, cube = LDS address of the wave's cube.
+records, wave-uniform), l2/lz/ly/lx0..3 = the values of the lane's ligand atoms (2p, 2p + 1), cube = LDS address of the wave's cube.
 """
 import os
 
@@ -28,15 +28,17 @@ def stage_a(h):
     out = []
     for t in range(2):
         i = i0 + 2 * t
+        # ligand atoms i, i + 1 = the two halves of the pair registers l2/lz/ly/lx[i / 2]: op_sel broadcasts the half
+        p = i // 2
         out += [
-            "v_pk_add_f32 v[252:253], %%[rs%d], %%[lz%d] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" % (g, i),
-            "v_pk_add_f32 v[254:255], %%[rs%d], %%[lz%d] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" % (g, i + 1),
-            "v_pk_fma_f32 v[252:253], %%[rz%d], %%[lz%d], v[252:253] op_sel_hi:[1,0,1]" % (g, i),
-            "v_pk_fma_f32 v[254:255], %%[rz%d], %%[lz%d], v[254:255] op_sel_hi:[1,0,1]" % (g, i + 1),
-            "v_pk_fma_f32 v[252:253], %%[ry%d], %%[lx%d], v[252:253] op_sel:[0,1,0] op_sel_hi:[1,1,1]" % (g, i),
-            "v_pk_fma_f32 v[254:255], %%[ry%d], %%[lx%d], v[254:255] op_sel:[0,1,0] op_sel_hi:[1,1,1]" % (g, i + 1),
-            "v_pk_fma_f32 v[252:253], %%[rx%d], %%[lx%d], v[252:253] op_sel_hi:[1,0,1]" % (g, i),
-            "v_pk_fma_f32 v[254:255], %%[rx%d], %%[lx%d], v[254:255] op_sel_hi:[1,0,1]" % (g, i + 1),
+            "v_pk_add_f32 v[252:253], %%[rs%d], %%[l2%d] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" % (g, p),
+            "v_pk_add_f32 v[254:255], %%[rs%d], %%[l2%d] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" % (g, p),
+            "v_pk_fma_f32 v[252:253], %%[rz%d], %%[lz%d], v[252:253] op_sel:[0,0,0] op_sel_hi:[1,0,1]" % (g, p),
+            "v_pk_fma_f32 v[254:255], %%[rz%d], %%[lz%d], v[254:255] op_sel:[0,1,0] op_sel_hi:[1,1,1]" % (g, p),
+            "v_pk_fma_f32 v[252:253], %%[ry%d], %%[ly%d], v[252:253] op_sel:[0,0,0] op_sel_hi:[1,0,1]" % (g, p),
+            "v_pk_fma_f32 v[254:255], %%[ry%d], %%[ly%d], v[254:255] op_sel:[0,1,0] op_sel_hi:[1,1,1]" % (g, p),
+            "v_pk_fma_f32 v[252:253], %%[rx%d], %%[lx%d], v[252:253] op_sel:[0,0,0] op_sel_hi:[1,0,1]" % (g, p),
+            "v_pk_fma_f32 v[254:255], %%[rx%d], %%[lx%d], v[254:255] op_sel:[0,1,0] op_sel_hi:[1,1,1]" % (g, p),
         ]
         out += ["v_cvt_u32_f32 v%d, v%d" % (cs + 4 * t + k, 252 + k) for k in range(4)]
     out += ["ds_read_u8 v%d, v%d" % (cs + k, cs + k) for k in range(8)]
@@ -63,6 +65,28 @@ def stage_c(h):
     return out
 
 
+def pose_block():
+    """Two of the lane's 8 ligand atoms posed at a time: l = A x + t' (the affine map of bm_apply, same operations and nesting,
+    so the culling kernel's boxes and the exact path's re-evaluation see the same bits), and |l|^2.  Operands: A0xy = {r00, r01},
+    A0zw = {r02, tx - cx}, ... (the lane's map, the translation already relative to the block's centre); X, Y, Z = the local
+    coordinates of atoms (2p, 2p + 1), wave-uniform; outputs LX, LY, LZ, L2 = the two atoms' values.  One statement per pair of
+    atoms: all four at once had 68 registers live and spilled."""
+    lines = []
+    for c, row in (("x", 0), ("y", 1), ("z", 2)):
+        d = "%%[l%s]" % c
+        # t = fma(r?2, z, t');  t = fma(r?1, y, t);  t = fma(r?0, x, t)
+        lines.append("v_pk_fma_f32 %s, %%[a%dzw], %%[z], %%[a%dzw] op_sel:[0,0,1] op_sel_hi:[0,1,1]" % (d, row, row))
+        lines.append("v_pk_fma_f32 %s, %%[a%dxy], %%[y], %s op_sel:[1,0,0] op_sel_hi:[1,1,1]" % (d, row, d))
+        lines.append("v_pk_fma_f32 %s, %%[a%dxy], %%[x], %s op_sel:[0,0,0] op_sel_hi:[0,1,1]" % (d, row, d))
+    lines.append("v_pk_mul_f32 %[l2], %[lz], %[lz]")
+    lines.append("v_pk_fma_f32 %[l2], %[ly], %[ly], %[l2]")
+    lines.append("v_pk_fma_f32 %[l2], %[lx], %[lx], %[l2]")
+    outs = ['[%s] "=&v"(%s)' % (name, arr) for name, arr in (("lx", "LX"), ("ly", "LY"), ("lz", "LZ"), ("l2", "L2"))]
+    ins = ['[a%d%s] "v"(A%d%s)' % (r, h, r, h) for r in range(3) for h in ("xy", "zw")]
+    ins += ['[%s] "v"(%s)' % (c, arr) for c, arr in (("x", "X"), ("y", "Y"), ("z", "Z"))]
+    return lines, outs, ins
+
+
 def main():
     lines = []
     for h in range(10):
@@ -78,18 +102,23 @@ def main():
     ops_in = []
     for name in ("rs", "rz", "ry", "rx"):
         ops_in += ['[%s%d] "v"(%s[%d])' % (name, g, {"rs": "Rs", "rz": "Rz", "ry": "Ry", "rx": "Rx"}[name], g) for g in range(4)]
-    ops_in += ['[lz%d] "v"(lz2[%d])' % (i, i) for i in range(8)]
-    ops_in += ['[lx%d] "v"(lxy[%d])' % (i, i) for i in range(8)]
+    for name, arr in (("l2", "L2"), ("lz", "LZ"), ("ly", "LY"), ("lx", "LX")):
+        ops_in += ['[%s%d] "v"(%s[%d])' % (name, p, arr, p) for p in range(4)]
     clobbers = ", ".join('"v%d"' % r for r in range(220, 256))
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.path.join(here, "..", "csrc", "kernels", "dfire_bm_batch.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by lightdock-rust_amd/tools/gen_bm_batch_asm.py -- do not edit; the generator's docstring explains the schedule.\n")
         f.write("// %d instructions: %d vector, %d LDS, %d waits.\n" % (len(lines), sum(l.startswith("v_") for l in lines), sum(l.startswith("ds_") for l in lines), sum(l.startswith("s_waitcnt") for l in lines)))
-        f.write("#define LD_BM_BATCH_ASM(SUM0, SUM1, Rs, Rz, Ry, Rx, lz2, lxy, CUBE) \\\n  asm volatile( \\\n" + body + " \\\n")
+        f.write("#define LD_BM_BATCH_ASM(SUM0, SUM1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX, CUBE) \\\n  asm volatile( \\\n" + body + " \\\n")
         f.write('    : [acc] "+v"(SUM0), [acc1] "+v"(SUM1) \\\n    : ' + ", \\\n      ".join(ops_in) + ', \\\n      [cube] "n"(CUBE) \\\n')
         f.write("    : " + clobbers + ', "memory")\n')
-    print("wrote", os.path.normpath(path), len(lines), "instructions")
+        plines, pouts, pins = pose_block()
+        f.write("\n// two of the lane's 8 ligand atoms posed: %d packed instructions\n" % len(plines))
+        f.write("#define LD_BM_POSE_ASM(LX, LY, LZ, L2, A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, X, Y, Z) \\\n  asm( \\\n")
+        f.write(" \\\n".join('    "%s\\n\\t"' % l for l in plines) + " \\\n")
+        f.write("    : " + ", \\\n      ".join(pouts) + " \\\n    : " + ", \\\n      ".join(pins) + ")\n")
+    print("wrote", os.path.normpath(path), len(lines), "+", len(plines), "instructions")
 
 
 if __name__ == "__main__":
