@@ -42,6 +42,19 @@ constexpr int kBmCullHitTiles = 4;              // hit list of a dfire_bm_cull w
 __host__ __device__ inline int bm_cull_hit_cap(int n_rt) { return kBmCullHitTiles * n_rt > 192 ? kBmCullHitTiles * n_rt : 192; }   // (a flush costs one atomic per tile pair)
 __host__ __device__ inline size_t bm_cull_wave_lds(int n_rt) { return ((size_t)bm_cull_hit_cap(n_rt) * 14 + (size_t)n_rt * 8 + 15) / 16 * 16; }
 constexpr float kBmBoxCut = 14400.0f * 1.00005f;  // (8 * 15 A)^2 in record units, padded for the rounding of the box test
+// A receptor subtile's box as the culling kernel keeps it in LDS: per axis the pair {lo, -hi}.  With the ligand subtile's box as
+// {-hi, lo} the two differences of an axis' gap -- lo_r - hi_l and lo_l - hi_r, the values axis_gap forms -- are ONE packed add.
+struct BmCullBox {
+    v2f x, y, z, unused;
+};
+static_assert(sizeof(BmCullBox) == sizeof(TiledBox), "same room in LDS");
+__device__ __forceinline__ float bm_cull_gap2(v2f lx, v2f ly, v2f lz, const BmCullBox &r) {   // = box_gap2, bit for bit
+    const v2f dx = r.x + lx, dy = r.y + ly, dz = r.z + lz;
+    const float gx = fmaxf(0.0f, fmaxf(dx.x, dx.y)), gy = fmaxf(0.0f, fmaxf(dy.x, dy.y)), gz = fmaxf(0.0f, fmaxf(dz.x, dz.y));
+    return gx * gx + gy * gy + gz * gz;
+}
+// v_writelane_b32 (value, lane: wave-uniform; the other lanes keep `old`): this compiler has the intrinsic but no builtin for it
+extern "C" __device__ int bm_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
 // row of the pass -> pose row, or -1 beyond the list of this launch / inactive
 __device__ __forceinline__ long long bm_pose_of(BmArgs *T, size_t listed) {
@@ -146,8 +159,8 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
-    TiledBox *s_sub = reinterpret_cast<TiledBox *>(s_cull);            // [n_rt * 8]
-    TiledBox *s_tile = s_sub + (size_t)n_rt * 8;                        // [n_rt]
+    BmCullBox *s_sub = reinterpret_cast<BmCullBox *>(s_cull);          // [n_rt * 8]
+    TiledBox *s_tile = reinterpret_cast<TiledBox *>(s_sub + (size_t)n_rt * 8);   // [n_rt]
     // per wave: the HITS (pose of the wave, receptor tile, block mask) of the item so far, room for kBmCullHitTiles * n_rt of
     // them (a pose adds at most n_rt; the list is flushed when the next pose might not fit), and per receptor tile a counter
     // and the first entry of the wave in that tile pair's list
@@ -161,7 +174,11 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     {
         static_assert(sizeof(TiledBox) == 32, "two 16-byte pieces");
         const uint4 *src_sub = reinterpret_cast<const uint4 *>(T->m.rec_sub), *src_tile = reinterpret_cast<const uint4 *>(T->m.rec_tile);
-        for (int k = threadIdx.x; k < n_rt * 16; k += kBmCullWaves * 64) reinterpret_cast<uint4 *>(s_sub)[k] = src_sub[k];
+        for (int k = threadIdx.x; k < n_rt * 8; k += kBmCullWaves * 64) {
+            const uint4 lo = src_sub[2 * k], hi = src_sub[2 * k + 1];   // a TiledBox: lo x y z ., hi x y z .
+            reinterpret_cast<uint4 *>(s_sub)[2 * k] = uint4{lo.x, hi.x ^ 0x80000000u, lo.y, hi.y ^ 0x80000000u};
+            reinterpret_cast<uint4 *>(s_sub)[2 * k + 1] = uint4{lo.z, hi.z ^ 0x80000000u, 0u, 0u};
+        }
         for (int k = threadIdx.x; k < n_rt * 2; k += kBmCullWaves * 64) reinterpret_cast<uint4 *>(s_tile)[k] = src_tile[k];
         __syncthreads();
     }
@@ -221,6 +238,10 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                       pose_lane(my_a2.x, g), pose_lane(my_a2.y, g), pose_lane(my_a2.z, g), pose_lane(my_a2.w, g)};
     };
 
+    // the tile's bounding sphere posed by all the item's poses at once: lane g, with the map it holds
+    float my_sx, my_sy, my_sz;
+    bm_apply(Affine{my_a0.x, my_a0.y, my_a0.z, my_a0.w, my_a1.x, my_a1.y, my_a1.z, my_a1.w, my_a2.x, my_a2.y, my_a2.z, my_a2.w}, sphere.x, sphere.y, sphere.z, my_sx, my_sy, my_sz);
+
     uint32_t n_hits = 0;                 // wave-uniform: hits listed and not flushed yet
     // ---- the list -> entries.  One LDS atomic per hit (its place among the wave's hits of the tile pair), ONE global atomic per
     // tile pair for the whole wave (the lists of a small complex have few heads: one returning atomic per pose and tile pair
@@ -261,16 +282,14 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         pose_of[g] = (long long)((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_pose, g) |
                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)my_pose >> 32), g) << 32);
         if (pose_of[g] < 0) continue;
-        const Affine A = affine_of(g);
         if (n_hits + (uint32_t)n_rt > (uint32_t)hit_cap) flush();
         // the hits of one ballot of receptor tiles, lane-distributed, written to the list together (one LDS store per lane
         // instead of a scalar branch, five register moves and two stores per hit)
         uint32_t held = 0;                  // wave-uniform
-        unsigned long long held_mask = 0ull;
-        uint32_t held_key = 0;
+        uint32_t held_lo = 0, held_hi = 0, held_key = 0;   // (lane k: hit k, written by v_writelane)
         auto put_held = [&]() {
             if ((uint32_t)lane < held) {
-                s_hmask[n_hits + (uint32_t)lane] = held_mask;
+                s_hmask[n_hits + (uint32_t)lane] = (unsigned long long)held_hi << 32 | held_lo;
                 s_hkey[n_hits + (uint32_t)lane] = held_key;
             }
             n_hits += held;
@@ -279,8 +298,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         {   // A tile whose bounding sphere stays beyond the cutoff of every receptor tile's box has nothing to list (most tiles
             // of a large ligand, in most poses): one point posed and one test per receptor tile instead of 64 atoms posed,
             // their boxes and the box tests.
-            float sx, sy, sz;
-            bm_apply(A, sphere.x, sphere.y, sphere.z, sx, sy, sz);
+            const float sx = pose_lane(my_sx, g), sy = pose_lane(my_sy, g), sz = pose_lane(my_sz, g);
             const float reach = 120.0f * 1.0001f + sphere.w + pad;   // (8 * 15 A, the sphere's radius, the affine map's error)
             bool any_near = false;
             for (int base = 0; base < n_rt && !any_near; base += 64) {
@@ -295,6 +313,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                 continue;
             }
         }
+        const Affine A = affine_of(g);
         float fx, fy, fz;
         bm_apply(A, loc.x, loc.y, loc.z, fx, fy, fz);
         const bool inside = fabsf(fx) <= ubound && fabsf(fy) <= ubound && fabsf(fz) <= ubound;
@@ -308,6 +327,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
             sub.lox -= pad; sub.loy -= pad; sub.loz -= pad;
             sub.hix += pad; sub.hiy += pad; sub.hiz += pad;
         }
+        const v2f sub_x{-sub.hix, sub.lox}, sub_y{-sub.hiy, sub.loy}, sub_z{-sub.hiz, sub.loz};
         BoxRegs whole = sub;   // (widening is monotone: the union of the widened subtile boxes IS the widened tile box)
         box_reduce64_from8(whole);
         whole.lox = lane63_f32(whole.lox); whole.loy = lane63_f32(whole.loy); whole.loz = lane63_f32(whole.loz);
@@ -320,30 +340,31 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
             if (base == 0) tile_near = lane < n_rt && box_gap2(whole, my_tile) <= kBmBoxCut;
             else if (base + lane < n_rt) tile_near = box_gap2(whole, s_tile[base + lane]) <= kBmBoxCut;
             unsigned long long rtmask = __ballot(tile_near);
-            while (rtmask) {
-                // four surviving tiles at a time: their subtile boxes are loaded together
-                int RTs[4], nk = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    RTs[k] = rtmask ? base + __ffsll(rtmask) - 1 : RTs[0];
-                    if (rtmask) nk++;
+            if (rtmask) {
+                // one surviving tile at a time, the next one's subtile boxes loaded while this one's are tested (the last trip loads
+                // its own again: no branch around the loads)
+                // (two copies of the step, the boxes alternating between two sets of registers: no moves)
+                int RT_a = base + __ffsll(rtmask) - 1, RT_b = RT_a;
+                rtmask &= rtmask - 1;
+                BmCullBox nb_a = s_sub[RT_a * 8 + bj], nb_b;
+                auto step = [&](int RT, const BmCullBox &nb, int &RT_next, BmCullBox &nb_next) {
+                    const bool more = rtmask != 0ull;
+                    RT_next = more ? base + __ffsll(rtmask) - 1 : RT;
                     rtmask &= rtmask - 1;
-                }
-                TiledBox nb[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) nb[k] = s_sub[RTs[k] * 8 + bj];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (k >= nk) break;
-                    const unsigned long long smask = __ballot(box_gap2(sub, nb[k]) <= kBmBoxCut);  // bit = ligand subtile (lane >> 3) * 8 + receptor subtile
+                    nb_next = s_sub[RT_next * 8 + bj];
+                    const unsigned long long smask = __ballot(bm_cull_gap2(sub_x, sub_y, sub_z, nb) <= kBmBoxCut);  // bit = ligand subtile (lane >> 3) * 8 + receptor subtile
                     if (smask) {   // hit `held` of this ballot stays in lane `held` until the ballot's tiles are done
-                        if (lane == (int)held) {
-                            held_mask = smask;
-                            held_key = (uint32_t)(g << 16 | RTs[k]);
-                        }
+                        held_lo = (uint32_t)bm_writelane((int)(uint32_t)smask, (int)held, (int)held_lo);
+                        held_hi = (uint32_t)bm_writelane((int)(uint32_t)(smask >> 32), (int)held, (int)held_hi);
+                        held_key = (uint32_t)bm_writelane(g << 16 | RT, (int)held, (int)held_key);
                         held++;
                     }
                     if (COUNT) tested += (uint32_t)__popcll(smask);
+                    return more;
+                };
+                for (;;) {
+                    if (!step(RT_a, nb_a, RT_b, nb_b)) break;
+                    if (!step(RT_b, nb_b, RT_a, nb_a)) break;
                 }
             }
             put_held();   // (a ballot's 64 receptor tiles make at most 64 hits)
