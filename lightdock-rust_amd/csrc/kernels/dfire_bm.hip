@@ -133,6 +133,11 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
         o[9] = (float)(k * 2.0 * (y * z + w * x));
         o[10] = (float)(k * (w * w - x * x - y * y + z * z));
         o[11] = (float)(kBmKappa * (tz - T->m.cz));
+        {   // the exact path's row: the pose's own numbers and its index, 64 bytes
+            double *e = T->rt_exact + listed * 8;
+            e[0] = tx; e[1] = ty; e[2] = tz; e[3] = w; e[4] = x; e[5] = y; e[6] = z;
+            e[7] = __longlong_as_double((long long)pose);
+        }
         {   // the pose's interface-flag words (the exact path sets bits, pose_energy_finish reads them)
             const int words = T->m.rec_flag_words + T->m.lig.flag_words;
             uint32_t *f = T->flags + pose * (size_t)words;
@@ -560,7 +565,7 @@ struct BmWaveCtx {
 // ---- the exact path.  A flagged cell reads its row's MARKER, (64 + i * 8 + j) << 50, instead of a table value.  After a
 // block's 64 adds the bits above 2^50 of a lane's sum are 0 (no flagged pair), 64 + pair (one: fourteen lanes in a
 // hundred) or at least 128 (several: four lanes in a thousand).  One flagged pair is named by the sum itself and goes
-// straight into the wave's list of pairs, a 64-bit item = entry of the pass | ligand atom << 32 | receptor atom << 48 that
+// straight into the wave's list of pairs, a 64-bit item = row of the pass | ligand atom << 32 | receptor atom << 48 that
 // needs nothing else of the job it came from: bm_exact_pairs evaluates the list between two jobs, a few hundred pairs at a
 // time, inlined (as a function of its own every call moved a hundred registers through scratch: a fifth of the kernel's
 // time), where little of the job loop's state is live.  With several flagged pairs the (entry, block) goes into a second list, and bm_recheck, at the
@@ -569,12 +574,9 @@ struct BmWaveCtx {
 // bm_exact_pairs: lane = flagged pair: exact_pair (f64, the reference's operation order, dfire_device.hpp), its value added
 // to the pose's fixed-point sum by an atomic, its interface flags set.  The lists live in global memory (in practice a few
 // lines per wave that never leave the L2).
-#ifndef LD_BM_DRAIN_AT
-#define LD_BM_DRAIN_AT 256
-#endif
-constexpr int kBmDrainAt = LD_BM_DRAIN_AT;   // flagged pairs a wave collects before it evaluates them
-__device__ __forceinline__ unsigned long long bm_pair_item(size_t entry, int la, int ra) {
-    return (unsigned long long)entry | (unsigned long long)la << 32 | (unsigned long long)ra << 48;
+constexpr int kBmDrainAt = 256;   // flagged pairs a wave collects before it evaluates them
+__device__ __forceinline__ unsigned long long bm_pair_item(uint32_t row, int la, int ra) {
+    return (unsigned long long)row | (unsigned long long)la << 32 | (unsigned long long)ra << 48;
 }
 
 __device__ __forceinline__ void bm_exact_pairs(BmArgs *T, unsigned long long *queue, uint32_t n_pairs, int lane) {
@@ -603,24 +605,36 @@ __device__ __forceinline__ void bm_exact_pairs(BmArgs *T, unsigned long long *qu
             la[u] = (int)((item[u] >> 32) & 0xffffu);
             ra[u] = (int)(item[u] >> 48);
             act[u] = act[u] && la[u] < T->m.lig.n_real && ra[u] < T->m.rec_n_real;   // (padding atoms of a block: nothing to add)
-            row[u] = act[u] ? T->ent_row[item[u] & 0xffffffffull] : 0;
+            row[u] = (size_t)(item[u] & 0xffffffffull);
         }
+        // a pair reads eight 16-byte pieces: its row of rt_exact (the pose), its two atoms' rows (scattered loads cost the
+        // memory pipeline a cache line per lane whatever their width: the 24 loads of 8 and 4 bytes this replaced were the
+        // exact path's time)
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        v2d pq[U][4], lq[U][2], rq[U][2];
 #pragma unroll
-        for (int u = 0; u < U; u++) pose[u] = act[u] ? (size_t)bm_pose_of(T, row[u]) : 0;
+        for (int u = 0; u < U; u++) {
+            const v2d *prow = reinterpret_cast<const v2d *>(T->rt_exact + (act[u] ? row[u] : 0) * 8);
+            const v2d *lrow = reinterpret_cast<const v2d *>(T->m.lig_exact + (size_t)(act[u] ? la[u] : 0) * 4);
+            const v2d *rrow = reinterpret_cast<const v2d *>(T->m.rec_exact + (size_t)(act[u] ? ra[u] : 0) * 4);
+#pragma unroll
+            for (int c = 0; c < 4; c++) pq[u][c] = prow[c];
+            lq[u][0] = lrow[0]; lq[u][1] = lrow[1];
+            rq[u][0] = rrow[0]; rq[u][1] = rrow[1];
+        }
         double pr[U][7], lc[U][3], rc[U][3];
         uint32_t lterm[U], rterm[U];
         int32_t rslot[U], lslot[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const double *prow = T->poses + pose[u] * T->stride;
-#pragma unroll
-            for (int c = 0; c < 7; c++) pr[u][c] = act[u] ? prow[c] : 1.0;
-            lc[u][0] = T->m.lig.x[la[u]]; lc[u][1] = T->m.lig.y[la[u]]; lc[u][2] = T->m.lig.z[la[u]];
-            rc[u][0] = T->m.rec_x[ra[u]]; rc[u][1] = T->m.rec_y[ra[u]]; rc[u][2] = T->m.rec_z[ra[u]];
-            lterm[u] = T->m.lig.tindex[la[u]];
-            rterm[u] = T->m.rec_tindex[ra[u]];
-            rslot[u] = T->m.rec_slot[ra[u]];
-            lslot[u] = T->m.lig.slot[la[u]];
+            pr[u][0] = pq[u][0].x; pr[u][1] = pq[u][0].y; pr[u][2] = pq[u][1].x; pr[u][3] = pq[u][1].y;
+            pr[u][4] = pq[u][2].x; pr[u][5] = pq[u][2].y; pr[u][6] = pq[u][3].x;
+            pose[u] = (size_t)__double_as_longlong(pq[u][3].y);
+            lc[u][0] = lq[u][0].x; lc[u][1] = lq[u][0].y; lc[u][2] = lq[u][1].x;
+            rc[u][0] = rq[u][0].x; rc[u][1] = rq[u][0].y; rc[u][2] = rq[u][1].x;
+            const unsigned long long lw = (unsigned long long)__double_as_longlong(lq[u][1].y), rw = (unsigned long long)__double_as_longlong(rq[u][1].y);
+            lterm[u] = (uint32_t)lw; lslot[u] = (int32_t)(lw >> 32);
+            rterm[u] = (uint32_t)rw; rslot[u] = (int32_t)(rw >> 32);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -683,7 +697,8 @@ __device__ __forceinline__ uint32_t bm_recheck(BmArgs *T, const unsigned char *l
     const size_t tp = entry / T->cap;
     const int lt = (int)(tp / (unsigned)n_rt), RT = (int)(tp % (unsigned)n_rt), ls = lt * 8 + a;
     // the lane's pose and block, as the batch saw them
-    const float4 *ap = reinterpret_cast<const float4 *>(T->rt) + (size_t)(act ? T->ent_row[entry] : 0u) * 3;   // (an idle lane's entry 0 may never have been written)
+    const uint32_t row = act ? T->ent_row[entry] : 0u;   // (an idle lane's entry 0 may never have been written)
+    const float4 *ap = reinterpret_cast<const float4 *>(T->rt) + (size_t)row * 3;
     const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
     const TiledBox box = T->m.rec_sub[(size_t)RT * 8 + b];
     const float cbx = 0.5f * (box.lox + box.hix), cby = 0.5f * (box.loy + box.hiy), cbz = 0.5f * (box.loz + box.hiz);
@@ -713,7 +728,7 @@ __device__ __forceinline__ uint32_t bm_recheck(BmArgs *T, const unsigned char *l
                 const unsigned long long m = __ballot(hit);
                 if (hit) {
                     const uint32_t at = n_pairs + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    queue[at] = bm_pair_item(entry, ls * 8 + i, RT * 64 + b * 8 + 2 * q + h);
+                    queue[at] = bm_pair_item(row, ls * 8 + i, RT * 64 + b * 8 + 2 * q + h);
                 }
                 n_pairs += (uint32_t)__popcll(m);
             }
@@ -945,7 +960,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 if (one) {   // the lane's one pair in a flagged cell (0.1 % of all pairs): the exact path
                     const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
                     const int pair = (int)mark - 64;
-                    queue[at] = bm_pair_item(row_base_entry + el, ls * 8 + (pair >> 3), RT * 64 + b * 8 + (pair & 7));
+                    queue[at] = bm_pair_item(cur.row, ls * 8 + (pair >> 3), RT * 64 + b * 8 + (pair & 7));
                 }
                 queued += (uint32_t)__popcll(m1);
                 if (__builtin_expect(m2 != 0ull, 0)) {
@@ -999,7 +1014,8 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
             if (DEBUG) dbg_t_drain += now() - td;
         }
         // (a few hundred pairs at a time: often enough that the other waves' batches hide its memory latencies -- everything at
-        // the wave's end was a 230 us tail of the whole launch -- and seldom enough that the calls do not count)
+        // the wave's end was a 230 us tail of the whole launch -- and seldom enough that the calls do not count.  A kernel of
+        // its own for the lists, after this one, took 120 us for what costs the waves 45 us each here: measured.)
         if (queued >= (uint32_t)kBmDrainAt) {
             const unsigned long long td = now();
             bm_exact_pairs(T, queue, queued, lane);
@@ -1086,15 +1102,20 @@ hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream) {
     return hipGetLastError();
 }
 
+static unsigned bm_pairs_groups(const BmLaunch &t) {   // persistent: what the chip holds
+    unsigned groups = (t.pairs_groups > 0 ? (unsigned)t.pairs_groups : 256u) * kBmGroupsPerCu;
+    if (const char *e = std::getenv("LIGHTDOCK_BM_HALF_OCCUPANCY")) {   // diagnostics: one workgroup per CU (one wave per SIMD)
+        if (std::atoi(e) == 1) groups /= kBmGroupsPerCu;
+    }
+    return groups;
+}
+
 hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
     hipLaunchKernelGGL(dfire_bm_plan, dim3(1), dim3(1024), 0, stream, t);
     hipLaunchKernelGGL(dfire_bm_census, dim3(128), dim3(kBmOrderWaves * 64), 0, stream, t);
     hipLaunchKernelGGL(dfire_bm_order, dim3(1), dim3(kBmOrderWaves * 64), 0, stream, t);
-    unsigned groups = (t.pairs_groups > 0 ? (unsigned)t.pairs_groups : 256u) * kBmGroupsPerCu;   // persistent: what the chip holds
-    if (const char *e = std::getenv("LIGHTDOCK_BM_HALF_OCCUPANCY")) {   // diagnostics: one workgroup per CU (one wave per SIMD)
-        if (std::atoi(e) == 1) groups /= kBmGroupsPerCu;
-    }
+    const unsigned groups = bm_pairs_groups(t);
     if (t.debug != nullptr) hipLaunchKernelGGL((dfire_bm_pairs<true>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
     else hipLaunchKernelGGL((dfire_bm_pairs<false>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
     return hipGetLastError();

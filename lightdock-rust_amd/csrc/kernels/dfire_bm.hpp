@@ -96,6 +96,7 @@ struct BmModel {
     int rec_flag_words = 0;
     // ligand
     TiledLigand lig;                            // f64, tile order (exact path, overflow tiles)
+    const double *lig_exact = nullptr, *rec_exact = nullptr;   // [atom][4]: x, y, z (f64) and {table term, interface-flag slot}: what the exact path reads of an atom, in two loads
     const float *lig_local = nullptr;           // [n_tiles*64][4]: x, y, z (angstrom, f32), 1.0 = real atom
     const uint32_t *lig_rowbase = nullptr;      // [n_tiles*64]: byte offset of the atom's type block in `rows`
     const float *lig_tile_sphere = nullptr;     // [n_tiles][4]: centre (local, angstrom) and radius (record units, rounded up) of a sphere around the tile
@@ -129,6 +130,7 @@ struct BmLaunch {
     int count_mode = 0;                    // 1: a counting launch -- full LUT, rows of ones, the sums are in-cutoff pair counts (-> count_partial)
     // workspace of the pass; "row" = row of the pass
     float *rt = nullptr;                   // [row][12]: the pose as an f32 affine map
+    double *rt_exact = nullptr;            // [row][8]: the pose as the exact path reads it: t, q (f64, the launch's own numbers), its index in the launch
     uint32_t *tp_count = nullptr;          // [n_tile_pairs], zeroed per launch
     uint32_t *ent_row = nullptr;           // [tile pair][cap]
     unsigned long long *ent_mask = nullptr;  // [tile pair][cap]

@@ -807,6 +807,22 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
             local[4 * i + 3] = 1.f;
         }
         M.lig_local = arena_.upload(local);
+        // what the exact path reads of an atom, together: x, y, z and {table term, interface-flag slot} in the fourth double's bytes
+        auto exact_rows = [&](const TiledSoA &m, bool is_receptor) {
+            const std::vector<uint32_t> &perm = is_receptor ? type_perm_rec_ : type_perm_lig_;
+            std::vector<double> rows(m.htype.size() * 4, 0.0);
+            for (size_t i = 0; i < m.htype.size(); i++) {
+                rows[4 * i] = m.hx[i];
+                rows[4 * i + 1] = m.hy[i];
+                rows[4 * i + 2] = m.hz[i];
+                const uint32_t term = m.htype[i] == kPad ? 0u : is_receptor ? tiled_rec_term(perm[m.htype[i]]) : tiled_lig_term(perm[m.htype[i]]);
+                const uint32_t words[2] = {term, (uint32_t)m.hslot[i]};
+                std::memcpy(&rows[4 * i + 3], words, 8);
+            }
+            return rows;
+        };
+        M.lig_exact = arena_.upload(exact_rows(lig, false));
+        M.rec_exact = arena_.upload(exact_rows(rec, true));
         // a sphere around every ligand tile (rotation invariant): centre of its box, radius to its farthest atom
         std::vector<float> sphere((size_t)lig.n_tiles * 4, 0.f);
         for (int t = 0; t < lig.n_tiles; t++) {
@@ -925,6 +941,7 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         t.first = off;
         t.n_poses = std::min(cap, n - off);
         t.rt = static_cast<float *>(ws_bm_rt_.ptr) + w * cap * 12;
+        t.rt_exact = reinterpret_cast<double *>(static_cast<float *>(ws_bm_rt_.ptr) + bm_sets(n) * cap * 12) + w * cap * 8;
         t.tp_count = static_cast<uint32_t *>(ws_bm_tp_count_.ptr) + w * (tile_pairs + kBmCounters + kBmCullQueueWords);
         t.job_count = t.tp_count + tile_pairs;
         t.job_next = t.tp_count + tile_pairs + 1;
@@ -1060,7 +1077,7 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         const size_t n_lt = (size_t)bm_.lig.n_tiles, n_rt = (size_t)bm_.rec_n_tiles, tile_pairs = n_lt * n_rt;
         const size_t cap = bm_pass_poses(n_poses), sets = bm_sets(n_poses);   // a second set only while two passes are in flight
         const size_t parts = tile_pairs * (cap / 64 + 1), waves = (size_t)n_cus_ * kBmWavesPerCu;
-        ws_bm_rt_.reserve(sets * cap * 12 * sizeof(float));
+        ws_bm_rt_.reserve(sets * cap * (12 * sizeof(float) + 8 * sizeof(double)));   // the f32 maps of every set, then the exact path's rows
         ws_bm_tp_count_.reserve(sets * (tile_pairs + kBmCounters + kBmCullQueueWords) * sizeof(uint32_t));   // + the launch's counters
         ws_bm_jobs_.reserve(sets * parts * 2 * sizeof(uint32_t));
         ws_bm_job_cost_.reserve(sets * parts * kBmJobRows * sizeof(uint32_t));

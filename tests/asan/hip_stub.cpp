@@ -84,6 +84,7 @@ hipError_t launch_dfire_packed(const PackedLaunch &t, hipStream_t) {
 size_t bm_pairs_lds_bytes() { return 0; }
 hipError_t launch_bm_pose(const BmLaunch &t, hipStream_t) {
     if (t.n_poses && t.rt) t.rt[12 * t.n_poses - 1] = 0.f;   // last slot of the pass's affine maps (the workspace of a pass goes by row)
+    if (t.n_poses && t.rt_exact) t.rt_exact[8 * t.n_poses - 1] = 0.0;
     return hipSuccess;
 }
 hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t) {
