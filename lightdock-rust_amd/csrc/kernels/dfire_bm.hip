@@ -836,6 +836,18 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                                                                               // together, for the gather's sake, the pair kernel took 200 us longer)
         const size_t row_base_entry = tp * T->cap + lo;
         if (DEBUG) dbg_t_scan += now() - dbg_tj;   // job set-up
+        // a batch's results, on their way out one batch late (see run_batch)
+        long long pending_val = 0;
+        uint32_t pending_item = 0xffffffffu, pending_row = 0;
+        auto flush_pending = [&]() {
+            // The (entry, ligand subtile)'s sum is complete with the entry's last block of the job: it goes to the pose's
+            // (row, ligand tile) sum by an integer atomic -- order-free, and no gather over 24 M scattered partial sums afterwards.
+            if (pending_item != 0xffffffffu) {
+                if (pending_item & 0x4000u) atomicAdd(reinterpret_cast<unsigned long long *>(T->tile_sum + (size_t)pending_row * n_lt + lt), (unsigned long long)pending_val);
+                else T->ent_partial[row_base + (pending_item & 0x3ffu)] = pending_val;
+            }
+            pending_item = 0xffffffffu;
+        };
         for (int b = 0; b < 8; b++) {
             if (!((any_bits >> b) & 1u)) continue;
             const unsigned long long dbg_tblk = now();
@@ -849,7 +861,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 for (int t = 0; t < kDma; t++) {
                     const int row = t * kDmaRows + dma_row;
                     const uint32_t src = (uint32_t)__shfl((int)row_src, row & 63, 64) + dma_piece;
-                    if (lane < kDmaRows * kRowPieces && row < kBmCubeRows)
+                    if (LD_BM_EXPERIMENT != 42 && lane < kDmaRows * kRowPieces && row < kBmCubeRows)
                         __builtin_amdgcn_global_load_lds((const global_u32 *)(table_rows + src), (lds_u32 *)(S.cube[wave] + t * (kDmaRows * kBmRowBytes)), 16, 0, 0);
                 }
             }
@@ -891,6 +903,11 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 if (wide_rows) row |= (((uint32_t)WS.rows_hi[el >> 2] >> (2 * (el & 3))) & 3u) << 16;
                 L.row = row;
                 const float4 *ap = reinterpret_cast<const float4 *>(T->rt) + (size_t)row * 3;
+                if (LD_BM_EXPERIMENT == 43 || LD_BM_EXPERIMENT == 45) {
+                    L.a0 = L.a1 = L.a2 = float4{1.f, 2.f, 3.f, (float)row};
+                    L.prev = 0;
+                    return L;
+                }
                 L.a0 = ap[0];
                 L.a1 = ap[1];
                 L.a2 = ap[2];
@@ -948,6 +965,9 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 // The batch's 64 pairs: dfire_bm_batch.inc (generated, tools/gen_bm_batch_asm.py).  Fixed-point sum: table
                 // values are integers (2^-k units, exact adds in any order); a flagged cell's slot holds the row's marker.
                 unsigned long long acc0 = 0ull, acc1 = 0ull;   // over the pairs with receptor atoms 0 2 4 6 / 1 3 5 7 of the subtile
+                if (LD_BM_EXPERIMENT >= 41 && LD_BM_EXPERIMENT <= 45 && LD_BM_EXPERIMENT != 42) {   // diagnostics: everything but the 64 pairs
+                    asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(Rs[0]), "v"(Rz[1]), "v"(Ry[2]), "v"(Rx[3]), "v"(L2[0]), "v"(LZ[1]), "v"(LY[2]), "v"(LX[3]));
+                } else
                 LD_BM_BATCH_ASM(acc0, acc1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX, kCube);
                 // each sum = marker bits + the true sum, |true sum| < 2^50 (32 pairs; the scale is chosen for that)
                 const long long sum0 = (long long)acc0, sum1 = (long long)acc1;
@@ -970,18 +990,19 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                     }
                     queued_blocks += (uint32_t)__popcll(m2);
                 }
-                // The (entry, ligand subtile)'s sum is complete with the entry's last block of the job: it goes to the pose's
-                // (row, ligand tile) sum by an integer atomic -- order-free, and no gather over 24 M scattered partial sums afterwards.
-                if (valid) {
-                    if (cur.item & 0x4000u) atomicAdd(reinterpret_cast<unsigned long long *>(T->tile_sum + (size_t)cur.row * n_lt + lt), (unsigned long long)(cur.prev + part));
-                    else T->ent_partial[row_base + el] = cur.prev + part;
-                }
+                // The lane's sum goes out at the start of the NEXT batch (flush_pending): memory operations complete in order, and
+                // the wait for the next batch's loads at the loop's top would wait for a store or atomic issued here, just before it,
+                // as well -- a round trip to the L2 per batch.  Issued in front of the following loads, it has a whole batch to complete.
+                pending_val = cur.prev + part;
+                pending_item = valid ? cur.item : 0xffffffffu;
+                pending_row = cur.row;
             };
             for (uint32_t done = 0; done < n_items; done += 64) {
                 if (DEBUG) dbg_batches++;
                 const unsigned long long dbg_tb = now();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this batch's loads (and, the first time, the block's rows) are in
                 const BatchLoads cur = next;
+                flush_pending();   // (in front of the next batch's loads)
                 // the rows' markers, over what the copy left in their slots (they name the PAIR: not part of the table); in a block
                 // with an atom that has an interface-flag slot also in place of bins 0 and 1: those pairs go to the exact path, which
                 // sets the flags (src/dfire.rs:339-342) and adds the value
@@ -1004,6 +1025,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 }
                 if (DEBUG) dbg_t_batch += now() - dbg_tb;
             }
+            flush_pending();   // (the next block's first loads read what this block's last batch wrote)
         }
         // The exact path, at the job's end only: no call inside the block and batch loops (the compiler keeps what lives across
         // a call site in scratch for the whole job), and the lists have room for everything one job can push.
