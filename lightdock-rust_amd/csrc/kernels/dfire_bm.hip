@@ -26,9 +26,6 @@ namespace {
 typedef const __attribute__((address_space(4))) BmLaunch BmArgs;
 #define LD_BM_ARGS ((BmArgs *)__builtin_amdgcn_kernarg_segment_ptr())
 
-#ifndef LD_BM_EXPERIMENT
-#define LD_BM_EXPERIMENT 0
-#endif
 #ifndef LD_BM_CULL_WAVES
 #define LD_BM_CULL_WAVES 4
 #endif
@@ -639,7 +636,6 @@ __device__ __forceinline__ void bm_exact_pairs(BmArgs *T, unsigned long long *qu
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (!act[u]) continue;
-            if (LD_BM_EXPERIMENT == 2 && pr[u][0] + lc[u][0] + rc[u][0] != 1.2345e300) continue;
             if (T->exact_pairs) atomicAdd(T->exact_pairs + row[u], 1u);
             // the ligand atom as the reference poses it (src/dfire.rs:282-302: pose_ligand_atom's operations), then exact_pair's
             const Quat q{pr[u][3], pr[u][4], pr[u][5], pr[u][6]};
@@ -861,7 +857,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 for (int t = 0; t < kDma; t++) {
                     const int row = t * kDmaRows + dma_row;
                     const uint32_t src = (uint32_t)__shfl((int)row_src, row & 63, 64) + dma_piece;
-                    if (LD_BM_EXPERIMENT != 42 && lane < kDmaRows * kRowPieces && row < kBmCubeRows)
+                    if (lane < kDmaRows * kRowPieces && row < kBmCubeRows)
                         __builtin_amdgcn_global_load_lds((const global_u32 *)(table_rows + src), (lds_u32 *)(S.cube[wave] + t * (kDmaRows * kBmRowBytes)), 16, 0, 0);
                 }
             }
@@ -903,11 +899,6 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 if (wide_rows) row |= (((uint32_t)WS.rows_hi[el >> 2] >> (2 * (el & 3))) & 3u) << 16;
                 L.row = row;
                 const float4 *ap = reinterpret_cast<const float4 *>(T->rt) + (size_t)row * 3;
-                if (LD_BM_EXPERIMENT == 43 || LD_BM_EXPERIMENT == 45) {
-                    L.a0 = L.a1 = L.a2 = float4{1.f, 2.f, 3.f, (float)row};
-                    L.prev = 0;
-                    return L;
-                }
                 L.a0 = ap[0];
                 L.a1 = ap[1];
                 L.a2 = ap[2];
@@ -965,9 +956,6 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 // The batch's 64 pairs: dfire_bm_batch.inc (generated, tools/gen_bm_batch_asm.py).  Fixed-point sum: table
                 // values are integers (2^-k units, exact adds in any order); a flagged cell's slot holds the row's marker.
                 unsigned long long acc0 = 0ull, acc1 = 0ull;   // over the pairs with receptor atoms 0 2 4 6 / 1 3 5 7 of the subtile
-                if (LD_BM_EXPERIMENT >= 41 && LD_BM_EXPERIMENT <= 45 && LD_BM_EXPERIMENT != 42) {   // diagnostics: everything but the 64 pairs
-                    asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(Rs[0]), "v"(Rz[1]), "v"(Ry[2]), "v"(Rx[3]), "v"(L2[0]), "v"(LZ[1]), "v"(LY[2]), "v"(LX[3]));
-                } else
                 LD_BM_BATCH_ASM(acc0, acc1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX, kCube);
                 // each sum = marker bits + the true sum, |true sum| < 2^50 (32 pairs; the scale is chosen for that)
                 const long long sum0 = (long long)acc0, sum1 = (long long)acc1;
@@ -1029,7 +1017,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         }
         // The exact path, at the job's end only: no call inside the block and batch loops (the compiler keeps what lives across
         // a call site in scratch for the whole job), and the lists have room for everything one job can push.
-        if (queued_blocks >= 64u && LD_BM_EXPERIMENT != 1) {
+        if (queued_blocks >= 64u) {
             const unsigned long long td = now();
             queued = bm_recheck(T, S.lut, queue_blocks, queued_blocks, queue, queued, lane);
             queued_blocks = 0;
@@ -1047,7 +1035,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
     }
     {
         const unsigned long long td = now();
-        if (queued_blocks && LD_BM_EXPERIMENT != 1) queued = bm_recheck(T, S.lut, queue_blocks, queued_blocks, queue, queued, lane);
+        if (queued_blocks) queued = bm_recheck(T, S.lut, queue_blocks, queued_blocks, queue, queued, lane);
         if (queued) bm_exact_pairs(T, queue, queued, lane);
         if (DEBUG) dbg_t_drain += now() - td;
     }
