@@ -173,6 +173,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     uint32_t *s_base = s_cnt + n_rt;                                                        // [n_rt]
     uint32_t *s_hkey = s_base + n_rt;                                                       // [hit_cap]: pose of the wave << 16 | receptor tile
     unsigned short *s_hrank = reinterpret_cast<unsigned short *>(s_hkey + hit_cap);         // [hit_cap]: place among the wave's hits of that tile pair
+    if (bm_rows(T) == 0) return;   // (a quiet GSO step)
     {
         static_assert(sizeof(TiledBox) == 32, "two 16-byte pieces");
         const uint4 *src_sub = reinterpret_cast<const uint4 *>(T->m.rec_sub), *src_tile = reinterpret_cast<const uint4 *>(T->m.rec_tile);
@@ -185,7 +186,10 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         __syncthreads();
     }
     const size_t rows = bm_rows(T);
-    const size_t n_items = (rows + kBmCullPoses - 1) / kBmCullPoses * (size_t)n_lt;
+    // poses per item: kBmCullPoses for a launch that fills the chip anyway; a small one (the late steps of a GSO: the count is
+    // known on the device only) takes 2, so that four times the waves share its latency -- a wave walks its poses one after the other
+    const int group_poses = rows * (size_t)n_lt >= (size_t)gridDim.x * kBmCullWaves * kBmCullPoses ? kBmCullPoses : 2;
+    const size_t n_items = (rows + group_poses - 1) / group_poses * (size_t)n_lt;
     const float ubound = T->m.ubound, pad = T->m.box_pad;
     const int bj = lane & 7;
     // The waves of a workgroup are independent (no barrier).  Items differ several times over in length (a ligand tile at
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     if (item >= queue_end) break;
     const size_t group = item / (unsigned)n_lt;
     const int lt = (int)(item % (unsigned)n_lt);
-    const size_t listed0 = group * kBmCullPoses;
+    const size_t listed0 = group * (size_t)group_poses;
 
     const int la = lt * 64 + lane;
     const float4 loc = reinterpret_cast<const float4 *>(T->m.lig_local)[la];
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     long long my_pose = -1;   // (only its sign is used: the workspace of a pass goes by row)
     const uint32_t my_row = (uint32_t)(listed0 + lane);
     float4 my_a0 = float4{0.f, 0.f, 0.f, 0.f}, my_a1 = my_a0, my_a2 = my_a0;
-    if (lane < kBmCullPoses && listed0 + lane < rows) my_pose = bm_pose_of(T, listed0 + lane);
+    if (lane < group_poses && listed0 + lane < rows) my_pose = bm_pose_of(T, listed0 + lane);
     if (my_pose >= 0) {
         const float4 *ap = reinterpret_cast<const float4 *>(T->rt + (size_t)my_row * 12);
         my_a0 = ap[0];
@@ -742,6 +746,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_rt = T->m.rec_n_tiles, n_lt = T->m.lig.n_tiles;
+    if (T->job_count[3] == 0) return;   // no job (a GSO step in which nothing moved): not 512 workgroups' copies of the LUT either -- that launch took 55 us
     {
         const uint8_t *lut = T->count_mode ? T->m.lut_full : T->m.lut;
         for (int i = tid; i < kBmLutBytes / 16; i += kBmWaves * 64) reinterpret_cast<uint4 *>(S.lut)[i] = reinterpret_cast<const uint4 *>(lut)[i];

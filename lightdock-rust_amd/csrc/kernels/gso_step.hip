@@ -151,17 +151,25 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
         // neighbours: luciferin strictly greater, distance strictly inside the vision range
         double total = 0.0;
         int cnt = 0;
-        for (int j = 0; j < N; j++) {
-            if (j == i) continue;
-            const double lj = sl[j];
-            if (li < lj) {
-                const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
-                const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
-                if (d2 > kFarD2) continue;  // sqrt(d2) > 5 >= vision range: cannot be a neighbour (exact: sqrt is monotone)
-                const double d = sqrt(d2);
-                if (d < vr) {
-                    total += lj - li;
-                    cnt++;
+        // (four luciferins read ahead of the tests: the loads of a trip are in flight together -- one at a time, each behind the
+        // previous candidate's branches, a thread of a live swarm waited 2 x N LDS latencies out)
+        for (int j0 = 0; j0 < N; j0 += 4) {
+            double l4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) l4[u] = sl[j0 + u < N ? j0 + u : i];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u;
+                const double lj = l4[u];
+                if (j < N && j != i && li < lj) {
+                    const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
+                    const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
+                    if (d2 > kFarD2) continue;  // sqrt(d2) > 5 >= vision range: cannot be a neighbour (exact: sqrt is monotone)
+                    const double d = sqrt(d2);
+                    if (d < vr) {
+                        total += lj - li;
+                        cnt++;
+                    }
                 }
             }
         }
