@@ -292,6 +292,34 @@ def test_gso_many_swarms_are_independent(pkg, scorers, orc):
     assert not np.array_equal(a0["target"], a3["target"])
 
 
+def test_gso_step_in_which_nothing_moves(pkg, scorers, orc):
+    """Late in a run whole swarms sit still: a swarm whose glowworms share one pose has no neighbours (luciferins equal,
+    src/glowworm.rs:104), so a step evaluates nothing -- the block-major kernels of such a step are launched with zero rows and
+    leave before their set-up.  Next to it a live swarm, whose steps must not notice."""
+    hip, cpu = scorers("1ppe")
+    base = case_positions("1ppe", orc)[:64]
+    still = np.repeat(base[3][None], 64, axis=0)
+    gso = pkg.GSO(hip, np.stack([still, base, still]))
+    quiet = pkg.GSO(hip, np.stack([still, still]))
+    refs = [orc.GSO(cpu, still), orc.GSO(cpu, base)]
+    for _ in range(6):
+        gso.step()
+        quiet.step()
+        for r in refs:
+            r.step()
+    evals_after_start = quiet.num_evals
+    quiet.step()
+    assert quiet.num_evals == evals_after_start == 2 * 64   # step 0 scores every glowworm once; nothing since
+    for s, r in ((0, refs[0]), (1, refs[1]), (2, refs[0])):
+        a, b = gso.read(s), r.state()
+        assert np.array_equal(a["n_neighbors"], b["n_neighbors"]) and np.array_equal(a["target"], b["target"])
+        assert np.array_equal(a["moved"], b["moved"])
+        assert rel_err(a["scoring"], b["scoring"]) < REL_TOL and rel_err(a["luciferin"], b["luciferin"]) < REL_TOL
+        assert np.max(np.abs(a["poses"] - b["poses"])) < 1e-12
+    assert not gso.read(0)["moved"].any() and np.array_equal(gso.read(0)["poses"], still)
+    assert np.array_equal(quiet.read(0)["scoring"], quiet.read(1)["scoring"])
+
+
 def test_cli_end_to_end_1azp(pkg, tmp_path):
     """The reference command line on the GPU engine: same stdout lines, same files
     (src/bin/lightdock-rust.rs:158-333)."""
