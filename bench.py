@@ -14,6 +14,8 @@ the hot path over one batch that already lives in HBM):
                   (weak scaling).
   1ppe            the same for the 1ppe system (config 2).
   1azp-dna        DNA scoring + receptor/ligand ANM on the 1azp system (config 4), same shape.
+  2uuy            DFIRE + receptor/ligand ANM (10 + 10 modes) on the 2uuy system: the pose-major DFIRE kernel (molecules that
+                  flex per pose stay off the block-major path).
   gso-1ppe        config 5 as written: --swarms (default 1024) x 200 glowworms of 1ppe DFIRE SHARDED
                   over the ranks, a step = one GSO step of every swarm (flag memset, K1 over the
                   glowworms that moved, tail, K2); total work fixed (strong scaling).
@@ -66,12 +68,17 @@ def load_case(name):
                             rec_nmodes=np.load(os.path.join(g, "rec_nm.npy")), rec_num_anm=10,
                             lig_nmodes=np.load(os.path.join(g, "lig_nm.npy")), lig_num_anm=10, use_anm=True),
                     pos=os.path.join(g, "initial_positions_0.dat"), cols=27)
+    if name == "2uuy":
+        return dict(method="dfire", rec=os.path.join(g, "lightdock_2UUY_rec.pdb"), lig=os.path.join(g, "lightdock_2UUY_lig.pdb"),
+                    kw=dict(rec_nmodes=np.load(os.path.join(g, "rec_nm.npy")), rec_num_anm=10,
+                            lig_nmodes=np.load(os.path.join(g, "lig_nm.npy")), lig_num_anm=10, use_anm=True),
+                    pos=os.path.join(g, "initial_positions_0.dat"), cols=27)
     raise SystemExit("unknown system " + name)
 
 
 WORKLOADS = {  # name -> (system, kind, default batch / swarms)
     "1k4c": ("1k4c", "k1", 8192), "1ppe": ("1ppe", "k1", 65536), "1azp-dna": ("1azp", "k1", 16384),
-    "gso-1ppe": ("1ppe", "gso", 1024), "gso-1k4c": ("1k4c", "gso", 64),
+    "gso-1ppe": ("1ppe", "gso", 1024), "gso-1k4c": ("1k4c", "gso", 64), "2uuy": ("2uuy", "k1", 16384),
 }
 
 
@@ -336,7 +343,7 @@ def main():
         total_evals = batch * args.steps * world
         scaling = "weak"
         shape = "%s %s pose-energy batch, %d poses/GPU/step, %d x %d atoms%s" % (
-            system, case["method"].upper(), batch, n_rec, n_lig, (", synthetic DCparams" + (" with bin 19 zeroed" if args.zero_last_bin else "")) if table is not None else ", 10 + 10 ANM modes")
+            system, case["method"].upper(), batch, n_rec, n_lig, ((", synthetic DCparams" + (" with bin 19 zeroed" if args.zero_last_bin else "")) if table is not None else "") + (", 10 + 10 ANM modes" if case["kw"].get("use_anm") else ""))
         extra = {"poses_per_step_per_gpu": batch, "nominal_pair_tests_per_pose": info["pair_tests_per_pose"],
                  "mean_pairs_in_cutoff": float(p_cut.mean()), "mean_8x8_blocks_evaluated": blocks}
         units_per_launch = batch

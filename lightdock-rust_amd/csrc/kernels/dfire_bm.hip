@@ -26,18 +26,11 @@ namespace {
 typedef const __attribute__((address_space(4))) BmLaunch BmArgs;
 #define LD_BM_ARGS ((BmArgs *)__builtin_amdgcn_kernarg_segment_ptr())
 
-#ifndef LD_BM_CULL_WAVES
-#define LD_BM_CULL_WAVES 4
-#endif
-constexpr int kBmCullWaves = LD_BM_CULL_WAVES;   // independent waves per dfire_bm_cull workgroup
 #ifndef LD_BM_CULL_POSES
 #define LD_BM_CULL_POSES 8
 #endif
 constexpr int kBmCullPoses = LD_BM_CULL_POSES;   // poses a wave of dfire_bm_cull walks with its ligand tile
 constexpr int kBmCullQueues = kBmCullQueueWords;   // (1k4c: 8 queues 695 us, 16 581, 32 388, 64 320, 128 ~310, 256 296, 512 316; static 337)   // counters the waves of dfire_bm_cull draw their items from
-constexpr int kBmCullHitTiles = 4;              // hit list of a dfire_bm_cull wave: room for this many poses that reach every receptor tile
-__host__ __device__ inline int bm_cull_hit_cap(int n_rt) { return kBmCullHitTiles * n_rt > 192 ? kBmCullHitTiles * n_rt : 192; }   // (a flush costs one atomic per tile pair)
-__host__ __device__ inline size_t bm_cull_wave_lds(int n_rt) { return ((size_t)bm_cull_hit_cap(n_rt) * 14 + (size_t)n_rt * 8 + 15) / 16 * 16; }
 constexpr float kBmBoxCut = 14400.0f * 1.00005f;  // (8 * 15 A)^2 in record units, padded for the rounding of the box test
 // A receptor subtile's box as the culling kernel keeps it in LDS: per axis the pair {lo, -hi}.  With the ligand subtile's box as
 // {-hi, lo} the two differences of an axis' gap -- lo_r - hi_l and lo_l - hi_r, the values axis_gap forms -- are ONE packed add.
@@ -163,7 +156,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
     BmCullBox *s_sub = reinterpret_cast<BmCullBox *>(s_cull);          // [n_rt * 8]
     TiledBox *s_tile = reinterpret_cast<TiledBox *>(s_sub + (size_t)n_rt * 8);   // [n_rt]
-    // per wave: the HITS (pose of the wave, receptor tile, block mask) of the item so far, room for kBmCullHitTiles * n_rt of
+    // per wave: the HITS (pose of the wave, receptor tile, block mask) of the item so far, room for bm_cull_hit_tiles(n_rt) * n_rt of
     // them (a pose adds at most n_rt; the list is flushed when the next pose might not fit), and per receptor tile a counter
     // and the first entry of the wave in that tile pair's list
     const int hit_cap = bm_cull_hit_cap(n_rt);

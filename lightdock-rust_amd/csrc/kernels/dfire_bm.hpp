@@ -81,6 +81,28 @@ constexpr int kBmCounters = 8;               // words behind tp_count, zeroed pe
                                              // part, jobs listed; behind them kBmCullQueueWords item counters of dfire_bm_cull
 constexpr int kBmCullQueueWords = 256;
 constexpr int kBmCostClasses = 80;           // jobs are drawn in classes of estimated length, longest first
+// dfire_bm_cull's LDS: the receptor's boxes (one per tile and 8 per tile of 32 bytes) and per wave of the workgroup a hit list
+// -- 14 bytes a hit, room for `hit tiles` poses that reach every receptor tile: a pose adds at most one hit per receptor tile, and
+// the list is flushed (one atomic per tile pair) when the next pose might not fit -- plus two words per receptor tile.  The list
+// shrinks for a receptor whose boxes leave less room; one of more than ~430 tiles (27 000 atoms) does not fit 160 KB with any
+// list: such a complex stays with the pose-major kernels (scorer.cpp, build_bm).
+#ifndef LD_BM_CULL_WAVES
+#define LD_BM_CULL_WAVES 4
+#endif
+constexpr int kBmCullWaves = LD_BM_CULL_WAVES;   // independent waves per dfire_bm_cull workgroup
+constexpr size_t kBmLdsPerCu = 160 * 1024;
+__host__ __device__ inline size_t bm_cull_lds_for(int n_rt, int hit_tiles) {
+    const int hit_cap = hit_tiles * n_rt > 192 ? hit_tiles * n_rt : 192;
+    return (size_t)n_rt * 9 * 32 + (size_t)kBmCullWaves * (((size_t)hit_cap * 14 + (size_t)n_rt * 8 + 15) / 16 * 16);
+}
+__host__ __device__ inline int bm_cull_hit_tiles(int n_rt) {   // 4 while they fit (every receptor up to 266 tiles), then 3, 2, 1
+    int k = 4;
+    while (k > 1 && bm_cull_lds_for(n_rt, k) + 1024 > kBmLdsPerCu) k--;
+    return k;
+}
+__host__ __device__ inline int bm_cull_hit_cap(int n_rt) { const int k = bm_cull_hit_tiles(n_rt); return k * n_rt > 192 ? k * n_rt : 192; }
+__host__ __device__ inline size_t bm_cull_wave_lds(int n_rt) { return ((size_t)bm_cull_hit_cap(n_rt) * 14 + (size_t)n_rt * 8 + 15) / 16 * 16; }
+__host__ __device__ inline size_t bm_cull_lds_bytes(int n_rt) { return bm_cull_lds_for(n_rt, bm_cull_hit_tiles(n_rt)); }
 constexpr size_t kBmMaxPassPoses = 262144;   // a job keeps its entries' rows of the pass as 18-bit numbers (LDS)
 
 struct BmModel {

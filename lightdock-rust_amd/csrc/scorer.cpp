@@ -716,6 +716,7 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     if (rec_anm_per_pose_) return;
     const TiledSoA &rec = tiled_rec_soa_, &lig = tiled_lig_soa_;
     if (rec.n_tiles > 1024 || lig.n_tiles > 1024) return;  // an item of the exact path names its atoms in 16 bits each
+    if (bm_cull_lds_bytes(rec.n_tiles) + 1024 > kBmLdsPerCu) return;  // the culling kernel keeps every receptor box in LDS: ~430 tiles at most
     // The exact path's values reach a pose's sum as 2^-40 fixed point (dfire_bm.hpp): a table that could overflow it, or
     // holds a value the reference would carry as inf / NaN (src/dfire.rs:338), stays with the pose-major kernels.
     for (size_t i = 0; i < LD_DFIRE_TABLE_LEN; i++)

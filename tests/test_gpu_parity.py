@@ -1034,19 +1034,21 @@ def _random_protein_pdb(path, n_atoms, seed, box):
     _write_pdb(path, atoms)
 
 
-@pytest.mark.parametrize("n_rec,box", [(4700, 30.0), (9000, 38.0), (17000, 47.0)])
+@pytest.mark.parametrize("n_rec,box", [(4700, 30.0), (9000, 38.0), (17000, 47.0), (21000, 50.5), (28500, 56.0)])
 def test_receptor_larger_than_one_ballot(pkg, orc, table, tmp_path, n_rec, box):
     """More than 64 receptor tiles (> 4096 atoms: the tile-box ballot loops) and a ligand that is
     not a multiple of 64, against the oracle and the all-pairs kernel.  141 tiles (9000 atoms) also take the culling
     kernel's LDS (receptor boxes + hit lists) past 64 KB, i.e. through hipFuncSetAttribute; 266 tiles (17 000 atoms) are
-    past the 255 an entry of the block-major path could name until round 4."""
+    past the 255 an entry of the block-major path could name until round 4; 329 tiles (21 000 atoms) leave the culling kernel's
+    waves a shorter hit list (its LDS holds every receptor box); 446 tiles (28 500 atoms) do not fit that LDS at all: the
+    pose-major kernel takes the complex, silently and with the same numbers."""
     rec, lig = str(tmp_path / "big_rec.pdb"), str(tmp_path / "big_lig.pdb")
     _random_protein_pdb(rec, n_rec, 1, box)
     _random_protein_pdb(lig, 333, 2, 8.0)
     cpu = orc.Scorer("dfire", rec, lig, rec_active=["A.LEU.2", "A.TRP.5"], lig_active=["A.ALA.1"], potential=table)
     hip = pkg.Scorer.from_pdb("dfire", rec, lig, rec_active=["A.LEU.2", "A.TRP.5"], lig_active=["A.ALA.1"], potential=table)
     assert hip.num_atoms(0) == n_rec and hip.num_atoms(1) == 333
-    assert hip.kernel_info()["pair_kernel_name"] == "dfire_bm_pairs"
+    assert hip.kernel_info()["pair_kernel_name"] == ("dfire_bm_pairs" if n_rec < 28000 else "dfire_packed_pairs")
     poses = pkg.synth.swarm(24, seed=9)
     poses[:, :3] *= 0.8
     want = cpu.energy_rows(poses)

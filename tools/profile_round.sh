@@ -4,7 +4,7 @@
 #   counting launch (--no-stats): every kernel of a sequence then runs the same number of times, and a mean per launch is one population.
 # Usage: bash tools/profile_round.sh <tag> [workload ...]     -> gpurun_out/prof_<tag>/<workload>/
 tag=${1:-r03}; shift
-wls=${@:-1k4c 1ppe 1azp-dna gso-1ppe gso-1k4c}
+wls=${@:-1k4c 1ppe 1azp-dna gso-1ppe gso-1k4c 2uuy}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for w in $wls; do
   out=gpurun_out/prof_$tag/$w; mkdir -p $out
