@@ -28,6 +28,7 @@ constexpr double kNmodesStep = 0.5;       // src/constants.rs:24
 constexpr double kLinearThreshold = 0.9995;  // src/constants.rs:11
 constexpr double kRho = 0.5, kGamma = 0.4, kBeta = 0.08, kMaxVision = 5.0;  // src/glowworm.rs:45-51
 constexpr int kMaxNeighbors = 5;
+constexpr int kGsoLanes = 8;  // lanes that share a glowworm's scans in a small launch
 constexpr double kFarD2 = 25.5;  // > kMaxVision^2: the vision range never exceeds 5 (src/glowworm.rs:91-96)
 constexpr int kMaxAnm = 64;
 
@@ -117,6 +118,9 @@ __device__ void anm_step(const double *mine, const double *other, double *out, i
     }
 }
 
+// LANES = lanes that share a glowworm's two scans over its swarm: 1 for a launch that fills the chip with glowworms (a thread
+// walks its swarm alone), 8 for a small one (see below).
+template <int LANES>
 __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int N = G.n_glowworms;
@@ -143,60 +147,119 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
     }
     __syncthreads();
 
-    for (int i = i_begin + threadIdx.x; i < i_end; i += blockDim.x) {
+    // A launch of few swarms is all latency -- a thread walks its swarm's N glowworms twice, 100 us for a step of N = 200 whatever
+    // else the step costs --, so there LANES = 8 lanes share a glowworm: the scans go 8 candidates at a time, and the lanes'
+    // verdicts come back IN ORDER through a ballot (the sums over the neighbours are f64 and taken in the reference's order,
+    // candidate by candidate, by every lane of the group alike).  With a thousand swarms the same shape loses: the draw and the
+    // move are then computed once per 8 glowworms of a wave instead of once per 64.
+    const int lane = (int)threadIdx.x & 63, sub = lane & (LANES - 1), group_shift = lane & ~(LANES - 1);
+    const int per_trip = (int)blockDim.x / LANES;
+    for (int first = i_begin; first < i_end; first += per_trip) {
+        const int own = first + (int)threadIdx.x / LANES;
+        const bool valid = own < i_end;
+        const int i = valid ? own : i_begin;   // (an idle group repeats the first glowworm and writes nothing)
         const double x1 = sx[i], y1 = sy[i], z1 = sz[i], li = sl[i];
-        G.luciferin_out[base + i] = li;
         const double vr = G.vision[base + i];
         const uint32_t done = G.step[base + i];
-        // neighbours: luciferin strictly greater, distance strictly inside the vision range
         double total = 0.0;
         int cnt = 0;
-        // (four luciferins read ahead of the tests: the loads of a trip are in flight together -- one at a time, each behind the
-        // previous candidate's branches, a thread of a live swarm waited 2 x N LDS latencies out)
-        for (int j0 = 0; j0 < N; j0 += 4) {
-            double l4[4];
+        int chosen = i;
+        if constexpr (LANES == 1) {
+            // neighbours: luciferin strictly greater, distance strictly inside the vision range
+            // (four luciferins read ahead of the tests: the loads of a trip are in flight together -- one at a time, each behind the
+            // previous candidate's branches, a thread of a live swarm waited 2 x N LDS latencies out)
+            for (int j0 = 0; j0 < N; j0 += 4) {
+                double l4[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) l4[u] = sl[j0 + u < N ? j0 + u : i];
+                for (int u = 0; u < 4; u++) l4[u] = sl[j0 + u < N ? j0 + u : i];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + u;
-                const double lj = l4[u];
-                if (j < N && j != i && li < lj) {
-                    const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
-                    const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
-                    if (d2 > kFarD2) continue;  // sqrt(d2) > 5 >= vision range: cannot be a neighbour (exact: sqrt is monotone)
-                    const double d = sqrt(d2);
-                    if (d < vr) {
-                        total += lj - li;
-                        cnt++;
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + u;
+                    const double lj = l4[u];
+                    if (j < N && j != i && li < lj) {
+                        const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
+                        const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
+                        if (d2 > kFarD2) continue;  // sqrt(d2) > 5 >= vision range: cannot be a neighbour (exact: sqrt is monotone)
+                        const double d = sqrt(d2);
+                        if (d < vr) {
+                            total += lj - li;
+                            cnt++;
+                        }
                     }
                 }
             }
-        }
-        // one draw per glowworm whether or not it has neighbours, swarm.rs:118
-        const uint64_t bits = stdrng_u64(key, (uint64_t)done * (uint64_t)N + (uint64_t)i);
-        const double rnd = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
-        int chosen = i;
-        if (cnt > 0) {  // while sum < r { sum += p[k]; k += 1 } -> neighbors[k-1], glowworm.rs:119-125
-            double sum = 0.0;
-            int k = 0;
-            for (int j = 0; j < N; j++) {
-                if (j == i) continue;
+            // one draw per glowworm whether or not it has neighbours, swarm.rs:118
+            const uint64_t bits = stdrng_u64(key, (uint64_t)done * (uint64_t)N + (uint64_t)i);
+            const double rnd = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+            if (cnt > 0) {  // while sum < r { sum += p[k]; k += 1 } -> neighbors[k-1], glowworm.rs:119-125
+                double sum = 0.0;
+                int k = 0;
+                for (int j = 0; j < N; j++) {
+                    if (j == i) continue;
+                    const double lj = sl[j];
+                    if (!(li < lj)) continue;
+                    const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
+                    const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
+                    if (d2 > kFarD2) continue;
+                    const double d = sqrt(d2);
+                    if (!(d < vr)) continue;
+                    // k == 0 with rnd == 0.0, or running out of neighbours, is a panic in the
+                    // reference (index under/overflow, probability ~2^-53); we keep the edge neighbour.
+                    if (k > 0 && !(sum < rnd)) break;
+                    sum += (lj - li) / total;
+                    chosen = j;
+                    k++;
+                }
+            }
+
+
+        } else {
+            // candidate j of the swarm: luciferin strictly greater, distance strictly inside the vision range
+            auto is_neighbour = [&](int j) {
+                if (j >= N || j == i) return false;
                 const double lj = sl[j];
-                if (!(li < lj)) continue;
+                if (!(li < lj)) return false;
                 const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
                 const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
-                if (d2 > kFarD2) continue;
-                const double d = sqrt(d2);
-                if (!(d < vr)) continue;
-                // k == 0 with rnd == 0.0, or running out of neighbours, is a panic in the
-                // reference (index under/overflow, probability ~2^-53); we keep the edge neighbour.
-                if (k > 0 && !(sum < rnd)) break;
-                sum += (lj - li) / total;
-                chosen = j;
-                k++;
+                if (d2 > kFarD2) return false;  // sqrt(d2) > 5 >= vision range: cannot be a neighbour (exact: sqrt is monotone)
+                return sqrt(d2) < vr;
+            };
+            for (int j0 = 0; j0 < N; j0 += LANES) {
+                uint32_t found = (uint32_t)(__ballot(is_neighbour(j0 + sub)) >> group_shift) & ((1u << LANES) - 1u);
+                while (found) {   // in the order of j
+                    const int j = j0 + __ffs(found) - 1;
+                    found &= found - 1;
+                    total += sl[j] - li;
+                    cnt++;
+                }
+            }
+            // one draw per glowworm whether or not it has neighbours, swarm.rs:118
+            const uint64_t bits = stdrng_u64(key, (uint64_t)done * (uint64_t)N + (uint64_t)i);
+            const double rnd = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+            if (__any(cnt > 0)) {  // while sum < r { sum += p[k]; k += 1 } -> neighbors[k-1], glowworm.rs:119-125
+                double sum = 0.0;
+                int k = 0;
+                bool stop = cnt == 0;
+                for (int j0 = 0; j0 < N; j0 += LANES) {
+                    uint32_t found = (uint32_t)(__ballot(!stop && is_neighbour(j0 + sub)) >> group_shift) & ((1u << LANES) - 1u);
+                    while (found && !stop) {
+                        const int j = j0 + __ffs(found) - 1;
+                        found &= found - 1;
+                        // (the reference's edge cases: see the single-lane loop)
+                        if (k > 0 && !(sum < rnd)) {
+                            stop = true;
+                            break;
+                        }
+                        sum += (sl[j] - li) / total;
+                        chosen = j;
+                        k++;
+                    }
+                    if (__all(stop)) break;
+                }
             }
         }
+        if (!valid || sub != 0) continue;   // one lane of the group moves the glowworm and writes its state
+        G.luciferin_out[base + i] = li;
 
         const double *mine = G.poses_in + (base + i) * G.pose_len;
         double *out = G.poses_out + (base + i) * G.pose_len;
@@ -239,11 +302,15 @@ size_t gso_kernel_lds_bytes(const GsoLaunch &g) { return (size_t)4 * g.n_glowwor
 hipError_t launch_gso_step(const GsoLaunch &g, hipStream_t stream) {
     if (g.n_swarms == 0) return hipSuccess;
     const int share = (g.n_glowworms + g.parts - 1) / g.parts;
-    int threads = (share + 63) / 64 * 64;
+    // eight lanes per glowworm while the launch is small enough to be all latency (up to 64 swarms of 200 on an MI355X)
+    const bool shared = (size_t)g.n_swarms * g.n_glowworms <= 16384;
+    int threads = (share * (shared ? kGsoLanes : 1) + 63) / 64 * 64;
     if (threads > 1024) threads = 1024;
     if (threads < 64) threads = 64;
-    hipLaunchKernelGGL(gso_movement_phase, dim3((unsigned)(g.n_swarms * g.parts)), dim3((unsigned)threads),
-                       gso_kernel_lds_bytes(g), stream, g);
+    if (shared)
+        hipLaunchKernelGGL(gso_movement_phase<kGsoLanes>, dim3((unsigned)(g.n_swarms * g.parts)), dim3((unsigned)threads), gso_kernel_lds_bytes(g), stream, g);
+    else
+        hipLaunchKernelGGL(gso_movement_phase<1>, dim3((unsigned)(g.n_swarms * g.parts)), dim3((unsigned)threads), gso_kernel_lds_bytes(g), stream, g);
     return hipGetLastError();
 }
 
