@@ -118,9 +118,44 @@ __device__ void anm_step(const double *mine, const double *other, double *out, i
     }
 }
 
-// LANES = lanes that share a glowworm's two scans over its swarm: 1 for a launch that fills the chip with glowworms (a thread
-// walks its swarm alone), 8 for a small one (see below).
-template <int LANES>
+// the glowworm's move towards `chosen` (src/glowworm.rs:127-157) and its state after the step
+__device__ __forceinline__ void gso_move(const GsoLaunch &G, size_t base, int i, double li, double vr, uint32_t done, int cnt, int chosen) {
+    G.luciferin_out[base + i] = li;
+
+    const double *mine = G.poses_in + (base + i) * G.pose_len;
+    double *out = G.poses_out + (base + i) * G.pose_len;
+    const bool moved = chosen != i;
+    if (moved) {
+        const double *other = G.poses_in + (base + chosen) * G.pose_len;
+        double dx = other[0] - mine[0], dy = other[1] - mine[1], dz = other[2] - mine[2];
+        const double norm = sqrt(dx * dx + dy * dy + dz * dz);
+        const double coef = kTranslationStep / norm;
+        dx *= coef; dy *= coef; dz *= coef;
+        out[0] = mine[0] + dx;
+        out[1] = mine[1] + dy;
+        out[2] = mine[2] + dz;
+        const Quat r = qslerp(Quat{mine[3], mine[4], mine[5], mine[6]}, Quat{other[3], other[4], other[5], other[6]},
+                              kRotationStep);
+        out[3] = r.w; out[4] = r.x; out[5] = r.y; out[6] = r.z;
+        if (G.anm_rec > 0) anm_step(mine + 7, other + 7, out + 7, G.anm_rec);
+        if (G.anm_lig > 0) anm_step(mine + 7 + G.anm_rec, other + 7 + G.anm_rec, out + 7 + G.anm_rec, G.anm_lig);
+    } else {
+        for (int c = 0; c < G.pose_len; c++) out[c] = mine[c];
+    }
+    // update_vision_range, glowworm.rs:91-96
+    const double v = vr + kBeta * (double)(kMaxNeighbors - cnt);
+    G.vision[base + i] = fmin(kMaxVision, fmax(0.0, v));
+    G.active[base + i] = moved ? 1 : 0;
+    G.n_neighbors[base + i] = cnt;
+    G.target[base + i] = chosen;
+    G.step[base + i] = done + 1;  // glowworm.rs:71
+    if (moved) {
+        atomicAdd(G.evals, 1ULL);  // integer: order independent
+        if (G.moved_list) G.moved_list[atomicAdd(G.moved_count, 1u)] = (uint32_t)(base + i);
+    }
+}
+
+// One thread per glowworm: what a launch that fills the chip with glowworms runs (a thread walks its swarm alone).
 __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int N = G.n_glowworms;
@@ -147,170 +182,180 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
     }
     __syncthreads();
 
-    // A launch of few swarms is all latency -- a thread walks its swarm's N glowworms twice, 100 us for a step of N = 200 whatever
-    // else the step costs --, so there LANES = 8 lanes share a glowworm: the scans go 8 candidates at a time, and the lanes'
-    // verdicts come back IN ORDER through a ballot (the sums over the neighbours are f64 and taken in the reference's order,
-    // candidate by candidate, by every lane of the group alike).  With a thousand swarms the same shape loses: the draw and the
-    // move are then computed once per 8 glowworms of a wave instead of once per 64.
-    const int lane = (int)threadIdx.x & 63, sub = lane & (LANES - 1), group_shift = lane & ~(LANES - 1);
-    const int per_trip = (int)blockDim.x / LANES;
-    for (int first = i_begin; first < i_end; first += per_trip) {
-        const int own = first + (int)threadIdx.x / LANES;
-        const bool valid = own < i_end;
-        const int i = valid ? own : i_begin;   // (an idle group repeats the first glowworm and writes nothing)
+    for (int i = i_begin + (int)threadIdx.x; i < i_end; i += (int)blockDim.x) {
         const double x1 = sx[i], y1 = sy[i], z1 = sz[i], li = sl[i];
         const double vr = G.vision[base + i];
         const uint32_t done = G.step[base + i];
         double total = 0.0;
         int cnt = 0;
         int chosen = i;
-        if constexpr (LANES == 1) {
-            // neighbours: luciferin strictly greater, distance strictly inside the vision range
-            // (four luciferins read ahead of the tests: the loads of a trip are in flight together -- one at a time, each behind the
-            // previous candidate's branches, a thread of a live swarm waited 2 x N LDS latencies out)
-            for (int j0 = 0; j0 < N; j0 += 4) {
-                double l4[4];
+        // neighbours: luciferin strictly greater, distance strictly inside the vision range
+        // (four luciferins read ahead of the tests: the loads of a trip are in flight together -- one at a time, each behind the
+        // previous candidate's branches, a thread of a live swarm waited 2 x N LDS latencies out)
+        for (int j0 = 0; j0 < N; j0 += 4) {
+            double l4[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) l4[u] = sl[j0 + u < N ? j0 + u : i];
+            for (int u = 0; u < 4; u++) l4[u] = sl[j0 + u < N ? j0 + u : i];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int j = j0 + u;
-                    const double lj = l4[u];
-                    if (j < N && j != i && li < lj) {
-                        const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
-                        const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
-                        if (d2 > kFarD2) continue;  // sqrt(d2) > 5 >= vision range: cannot be a neighbour (exact: sqrt is monotone)
-                        const double d = sqrt(d2);
-                        if (d < vr) {
-                            total += lj - li;
-                            cnt++;
-                        }
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u;
+                const double lj = l4[u];
+                if (j < N && j != i && li < lj) {
+                    const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
+                    const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
+                    if (d2 > kFarD2) continue;  // sqrt(d2) > 5 >= vision range: cannot be a neighbour (exact: sqrt is monotone)
+                    const double d = sqrt(d2);
+                    if (d < vr) {
+                        total += lj - li;
+                        cnt++;
                     }
                 }
             }
-            // one draw per glowworm whether or not it has neighbours, swarm.rs:118
-            const uint64_t bits = stdrng_u64(key, (uint64_t)done * (uint64_t)N + (uint64_t)i);
-            const double rnd = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
-            if (cnt > 0) {  // while sum < r { sum += p[k]; k += 1 } -> neighbors[k-1], glowworm.rs:119-125
-                double sum = 0.0;
-                int k = 0;
-                for (int j = 0; j < N; j++) {
-                    if (j == i) continue;
-                    const double lj = sl[j];
-                    if (!(li < lj)) continue;
-                    const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
-                    const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
-                    if (d2 > kFarD2) continue;
-                    const double d = sqrt(d2);
-                    if (!(d < vr)) continue;
-                    // k == 0 with rnd == 0.0, or running out of neighbours, is a panic in the
-                    // reference (index under/overflow, probability ~2^-53); we keep the edge neighbour.
-                    if (k > 0 && !(sum < rnd)) break;
-                    sum += (lj - li) / total;
+        }
+        // one draw per glowworm whether or not it has neighbours, swarm.rs:118
+        const uint64_t bits = stdrng_u64(key, (uint64_t)done * (uint64_t)N + (uint64_t)i);
+        const double rnd = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+        if (cnt > 0) {  // while sum < r { sum += p[k]; k += 1 } -> neighbors[k-1], glowworm.rs:119-125
+            double sum = 0.0;
+            int k = 0;
+            for (int j = 0; j < N; j++) {
+                if (j == i) continue;
+                const double lj = sl[j];
+                if (!(li < lj)) continue;
+                const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
+                const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
+                if (d2 > kFarD2) continue;
+                const double d = sqrt(d2);
+                if (!(d < vr)) continue;
+                // k == 0 with rnd == 0.0, or running out of neighbours, is a panic in the
+                // reference (index under/overflow, probability ~2^-53); we keep the edge neighbour.
+                if (k > 0 && !(sum < rnd)) break;
+                sum += (lj - li) / total;
+                chosen = j;
+                k++;
+            }
+        }
+
+
+        gso_move(G, base, i, li, vr, done, cnt, chosen);
+    }
+}
+
+// The same step for a launch of few swarms, which is all latency -- a thread walks its swarm's N glowworms twice, 100 us for a
+// step of N = 200 whatever else the step costs.  Here kGsoLanes lanes share a glowworm's scans: 8 candidates at a time, the
+// lanes' verdicts back IN ORDER through a ballot (the sums over the neighbours are f64 and taken in the reference's order,
+// candidate by candidate, by every lane of the group alike); the draw and the move stay with a THREAD per glowworm (done by
+// the groups they were computed once per 8 glowworms of a wave instead of once per 64: a step of 1024 quiet swarms took twice
+// as long), the hand-over goes through LDS.  Measured on one box, 1024 swarms x 200 of 1ppe, step time quiet / 1 % alive / all
+// alive: a thread per glowworm 0.062 / 0.310 / 5.35 ms, this kernel 0.087 / 0.278 / 5.45; 64 swarms of 1k4c: 1.447 against
+// 1.396 ms.  So: this one up to 16 384 glowworms, the other beyond.
+__global__ __launch_bounds__(1024) void gso_movement_phased(const GsoLaunch G) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    const int N = G.n_glowworms;
+    double *sx = sh, *sy = sh + N, *sz = sh + 2 * N, *sl = sh + 3 * N;
+    double *s_rnd = sh + 4 * N;   // per glowworm of this workgroup's share: its draw, its neighbour count, the neighbour it moves towards
+    int *s_cnt = reinterpret_cast<int *>(sh + 5 * N), *s_chosen = s_cnt + N;
+    const int swarm = blockIdx.x / G.parts, part = blockIdx.x % G.parts;
+    const size_t base = (size_t)swarm * N;
+    const uint32_t *key = G.rng_key + 8 * swarm;
+    const int share = (N + G.parts - 1) / G.parts;
+    const int i_begin = part * share, i_end = min(N, i_begin + share), n_mine = i_end - i_begin;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        sl[i] = (1.0 - kRho) * G.luciferin_in[base + i] + kGamma * G.scoring[base + i];  // glowworm.rs:70
+        const double *row = G.poses_in + (base + i) * G.pose_len;
+        sx[i] = row[0];
+        sy[i] = row[1];
+        sz[i] = row[2];
+    }
+    // the draws need nothing of the scans: one per glowworm whether or not it has neighbours, swarm.rs:118
+    for (int t = threadIdx.x; t < n_mine; t += blockDim.x) {
+        const int i = i_begin + t;
+        const uint64_t bits = stdrng_u64(key, (uint64_t)G.step[base + i] * (uint64_t)N + (uint64_t)i);
+        s_rnd[t] = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+    }
+    __syncthreads();
+    constexpr int LANES = kGsoLanes;
+    const int lane = (int)threadIdx.x & 63, sub = lane & (LANES - 1), group_shift = lane & ~(LANES - 1);
+    const int per_trip = (int)blockDim.x / LANES;
+    for (int first = 0; first < n_mine; first += per_trip) {
+        const int t = first + (int)threadIdx.x / LANES;
+        const bool valid = t < n_mine;
+        const int i = i_begin + (valid ? t : 0);
+        const double x1 = sx[i], y1 = sy[i], z1 = sz[i], li = sl[i];
+        const double vr = G.vision[base + i];
+        auto is_neighbour = [&](int j) {   // luciferin strictly greater, distance strictly inside the vision range
+            if (j >= N || j == i) return false;
+            const double lj = sl[j];
+            if (!(li < lj)) return false;
+            const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
+            const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
+            if (d2 > kFarD2) return false;
+            return sqrt(d2) < vr;
+        };
+        double total = 0.0;
+        int cnt = 0;
+        for (int j0 = 0; j0 < N; j0 += LANES) {
+            uint32_t found = (uint32_t)(__ballot(is_neighbour(j0 + sub)) >> group_shift) & ((1u << LANES) - 1u);
+            while (found) {   // in the order of j
+                const int j = j0 + __ffs(found) - 1;
+                found &= found - 1;
+                total += sl[j] - li;
+                cnt++;
+            }
+        }
+        int chosen = i;
+        if (__any(cnt > 0)) {  // while sum < r { sum += p[k]; k += 1 } -> neighbors[k-1], glowworm.rs:119-125
+            const double rnd = s_rnd[valid ? t : 0];
+            double sum = 0.0;
+            int k = 0;
+            bool stop = cnt == 0;
+            for (int j0 = 0; j0 < N; j0 += LANES) {
+                uint32_t found = (uint32_t)(__ballot(!stop && is_neighbour(j0 + sub)) >> group_shift) & ((1u << LANES) - 1u);
+                while (found && !stop) {
+                    const int j = j0 + __ffs(found) - 1;
+                    found &= found - 1;
+                    if (k > 0 && !(sum < rnd)) {
+                        stop = true;
+                        break;
+                    }
+                    sum += (sl[j] - li) / total;
                     chosen = j;
                     k++;
                 }
-            }
-
-
-        } else {
-            // candidate j of the swarm: luciferin strictly greater, distance strictly inside the vision range
-            auto is_neighbour = [&](int j) {
-                if (j >= N || j == i) return false;
-                const double lj = sl[j];
-                if (!(li < lj)) return false;
-                const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
-                const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
-                if (d2 > kFarD2) return false;  // sqrt(d2) > 5 >= vision range: cannot be a neighbour (exact: sqrt is monotone)
-                return sqrt(d2) < vr;
-            };
-            for (int j0 = 0; j0 < N; j0 += LANES) {
-                uint32_t found = (uint32_t)(__ballot(is_neighbour(j0 + sub)) >> group_shift) & ((1u << LANES) - 1u);
-                while (found) {   // in the order of j
-                    const int j = j0 + __ffs(found) - 1;
-                    found &= found - 1;
-                    total += sl[j] - li;
-                    cnt++;
-                }
-            }
-            // one draw per glowworm whether or not it has neighbours, swarm.rs:118
-            const uint64_t bits = stdrng_u64(key, (uint64_t)done * (uint64_t)N + (uint64_t)i);
-            const double rnd = (double)(bits >> 11) * (1.0 / 9007199254740992.0);
-            if (__any(cnt > 0)) {  // while sum < r { sum += p[k]; k += 1 } -> neighbors[k-1], glowworm.rs:119-125
-                double sum = 0.0;
-                int k = 0;
-                bool stop = cnt == 0;
-                for (int j0 = 0; j0 < N; j0 += LANES) {
-                    uint32_t found = (uint32_t)(__ballot(!stop && is_neighbour(j0 + sub)) >> group_shift) & ((1u << LANES) - 1u);
-                    while (found && !stop) {
-                        const int j = j0 + __ffs(found) - 1;
-                        found &= found - 1;
-                        // (the reference's edge cases: see the single-lane loop)
-                        if (k > 0 && !(sum < rnd)) {
-                            stop = true;
-                            break;
-                        }
-                        sum += (sl[j] - li) / total;
-                        chosen = j;
-                        k++;
-                    }
-                    if (__all(stop)) break;
-                }
+                if (__all(stop)) break;
             }
         }
-        if (!valid || sub != 0) continue;   // one lane of the group moves the glowworm and writes its state
-        G.luciferin_out[base + i] = li;
-
-        const double *mine = G.poses_in + (base + i) * G.pose_len;
-        double *out = G.poses_out + (base + i) * G.pose_len;
-        const bool moved = chosen != i;
-        if (moved) {
-            const double *other = G.poses_in + (base + chosen) * G.pose_len;
-            double dx = other[0] - mine[0], dy = other[1] - mine[1], dz = other[2] - mine[2];
-            const double norm = sqrt(dx * dx + dy * dy + dz * dz);
-            const double coef = kTranslationStep / norm;
-            dx *= coef; dy *= coef; dz *= coef;
-            out[0] = mine[0] + dx;
-            out[1] = mine[1] + dy;
-            out[2] = mine[2] + dz;
-            const Quat r = qslerp(Quat{mine[3], mine[4], mine[5], mine[6]}, Quat{other[3], other[4], other[5], other[6]},
-                                  kRotationStep);
-            out[3] = r.w; out[4] = r.x; out[5] = r.y; out[6] = r.z;
-            if (G.anm_rec > 0) anm_step(mine + 7, other + 7, out + 7, G.anm_rec);
-            if (G.anm_lig > 0) anm_step(mine + 7 + G.anm_rec, other + 7 + G.anm_rec, out + 7 + G.anm_rec, G.anm_lig);
-        } else {
-            for (int c = 0; c < G.pose_len; c++) out[c] = mine[c];
+        if (valid && sub == 0) {
+            s_cnt[t] = cnt;
+            s_chosen[t] = chosen;
         }
-        // update_vision_range, glowworm.rs:91-96
-        const double v = vr + kBeta * (double)(kMaxNeighbors - cnt);
-        G.vision[base + i] = fmin(kMaxVision, fmax(0.0, v));
-        G.active[base + i] = moved ? 1 : 0;
-        G.n_neighbors[base + i] = cnt;
-        G.target[base + i] = chosen;
-        G.step[base + i] = done + 1;  // glowworm.rs:71
-        if (moved) {
-            atomicAdd(G.evals, 1ULL);  // integer: order independent
-            if (G.moved_list) G.moved_list[atomicAdd(G.moved_count, 1u)] = (uint32_t)(base + i);
-        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_mine; t += blockDim.x) {
+        const int i = i_begin + t;
+        gso_move(G, base, i, sl[i], G.vision[base + i], G.step[base + i], s_cnt[t], s_chosen[t]);
     }
 }
 
 }  // namespace
 
-size_t gso_kernel_lds_bytes(const GsoLaunch &g) { return (size_t)4 * g.n_glowworms * sizeof(double); }
+size_t gso_kernel_lds_bytes(const GsoLaunch &g) { return (size_t)6 * g.n_glowworms * sizeof(double); }   // positions, luciferins; the phased kernel's hand-over
 
 hipError_t launch_gso_step(const GsoLaunch &g, hipStream_t stream) {
     if (g.n_swarms == 0) return hipSuccess;
     const int share = (g.n_glowworms + g.parts - 1) / g.parts;
-    // eight lanes per glowworm while the launch is small enough to be all latency (up to 64 swarms of 200 on an MI355X)
-    const bool shared = (size_t)g.n_swarms * g.n_glowworms <= 16384;
-    int threads = (share * (shared ? kGsoLanes : 1) + 63) / 64 * 64;
-    if (threads > 1024) threads = 1024;
-    if (threads < 64) threads = 64;
-    if (shared)
-        hipLaunchKernelGGL(gso_movement_phase<kGsoLanes>, dim3((unsigned)(g.n_swarms * g.parts)), dim3((unsigned)threads), gso_kernel_lds_bytes(g), stream, g);
-    else
-        hipLaunchKernelGGL(gso_movement_phase<1>, dim3((unsigned)(g.n_swarms * g.parts)), dim3((unsigned)threads), gso_kernel_lds_bytes(g), stream, g);
+    const bool small = (size_t)g.n_swarms * g.n_glowworms <= 16384;   // (up to 64 swarms of 200 on an MI355X: see gso_movement_phased)
+    const char *mode = std::getenv("LIGHTDOCK_GSO_K2");   // diagnostics: "single" / "phased" whatever the size
+    const std::string m = mode ? mode : "";
+    if (m == "phased" || (m != "single" && small)) {
+        int pt = (share * kGsoLanes + 63) / 64 * 64;
+        pt = pt > 1024 ? 1024 : pt;
+        hipLaunchKernelGGL(gso_movement_phased, dim3((unsigned)(g.n_swarms * g.parts)), dim3((unsigned)pt), gso_kernel_lds_bytes(g), stream, g);
+    } else {
+        int pt = (share + 63) / 64 * 64;
+        pt = pt > 1024 ? 1024 : pt;
+        hipLaunchKernelGGL(gso_movement_phase, dim3((unsigned)(g.n_swarms * g.parts)), dim3((unsigned)pt), gso_kernel_lds_bytes(g), stream, g);
+    }
     return hipGetLastError();
 }
 
