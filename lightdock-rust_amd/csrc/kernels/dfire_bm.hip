@@ -102,6 +102,11 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
         const size_t words = (size_t)T->m.lig.n_tiles * T->m.rec_n_tiles + kBmCounters + kBmCullQueueWords;
         for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < words; k += (size_t)gridDim.x * 256) T->tp_count[k] = 0u;
     }
+    {   // the (row, ligand tile) sums of the pass: one contiguous range, cleared by consecutive threads (a thread clearing its own
+        // row's n_lt words wrote 64 different lines per store)
+        const size_t sums = rows * (size_t)T->m.lig.n_tiles;
+        for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < sums; k += (size_t)gridDim.x * 256) T->tile_sum[k] = 0;
+    }
     for (size_t listed = (size_t)blockIdx.x * 256 + threadIdx.x; listed < rows; listed += (size_t)gridDim.x * 256) {
         const long long p = bm_pose_of(T, listed);
         if (p < 0) continue;
@@ -134,7 +139,6 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
             for (int k = 0; k < words; k++) f[k] = 0u;
         }
         if (T->exact_fix) T->exact_fix[listed] = 0;
-        for (int lt = 0; lt < T->m.lig.n_tiles; lt++) T->tile_sum[listed * (size_t)T->m.lig.n_tiles + lt] = 0;
         if (T->exact_pairs) T->exact_pairs[listed] = 0;
     }
 }
@@ -1051,24 +1055,36 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
 }
 
 // ---------------------------------------------------------------------------------------------
-// dfire_bm_gather: thread = row of the pass: the pose's (row, ligand tile) sums -- integers, filled by the pair kernel's
-// atomics, each below 2^61 -- added as f64 in tile order (a pose's total can pass 63 bits for an extreme table), plus the
+// dfire_bm_gather: eight lanes = row of the pass: the pose's (row, ligand tile) sums -- integers, filled by the pair kernel's
+// atomics, each below 2^61 -- added as f64 in a fixed order (a pose's total can pass 63 bits for an extreme table), plus the
 // exact path's sum.  A counting launch (count_mode) sums ones.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dfire_bm_gather(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
     const int n_lt = T->m.lig.n_tiles;
     const size_t n_rows = bm_rows(T);
-    for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < n_rows; row += (size_t)gridDim.x * 256) {
-        const long long pp = bm_pose_of(T, row);
-        if (pp < 0) continue;
-        const size_t pose = (size_t)pp;
+    // eight lanes per row, each every eighth tile sum (consecutive lanes read consecutive words); the sums are integers, their f64
+    // images added over the eight lanes in a fixed tree
+    const int sub = (int)threadIdx.x & 7;
+    const size_t rows_per_trip = (size_t)gridDim.x * 32;
+    for (size_t first = (size_t)blockIdx.x * 32; first < n_rows; first += rows_per_trip) {   // (whole waves stay together for the shuffles)
+        const size_t row = first + threadIdx.x / 8;
+        const bool valid = row < n_rows;
+        const long long pp = valid ? bm_pose_of(T, row) : -1;
         double units = 0.0;
         uint32_t tested = 0;
-        for (int lt = 0; lt < n_lt; lt++) {
-            units += (double)T->tile_sum[row * (size_t)n_lt + lt];
-            if (T->count_mode && T->tile_tested) tested += T->tile_tested[row * (size_t)n_lt + lt];
+        if (pp >= 0)
+            for (int lt = sub; lt < n_lt; lt += 8) {
+                units += (double)T->tile_sum[row * (size_t)n_lt + lt];
+                if (T->count_mode && T->tile_tested) tested += T->tile_tested[row * (size_t)n_lt + lt];
+            }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+            units += __shfl_xor(units, off, 64);
+            tested += (uint32_t)__shfl_xor((int)tested, off, 64);
         }
+        if (pp < 0 || sub != 0) continue;
+        const size_t pose = (size_t)pp;
         units += (double)T->exact_fix[row];
         if (T->count_mode) {   // (pair counts stay far below 2^53: exact)
             T->count_partial[pose] = (uint32_t)units;
@@ -1131,7 +1147,7 @@ hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
 
 hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    hipLaunchKernelGGL(dfire_bm_gather, dim3((unsigned)std::min<size_t>((t.n_poses + 255) / 256, 4096)), dim3(256), 0, stream, t);
+    hipLaunchKernelGGL(dfire_bm_gather, dim3((unsigned)std::min<size_t>((t.n_poses + 31) / 32, 8192)), dim3(256), 0, stream, t);   // 8 lanes per row
     return hipGetLastError();
 }
 
