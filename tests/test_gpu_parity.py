@@ -185,8 +185,8 @@ def test_full_size_batch_properties(pkg, scorers, orc):
 
 
 def test_batch_larger_than_one_block_major_pass(pkg, scorers, orc):
-    """20 000 poses of 1k4c: more than one pass of the block-major path holds (17 408 for this complex's 2 808 tile pairs), so
-    the batch runs as two passes, 17 408 + 2 592, on two streams with two workspace sets -- by the library's own rule, no
+    """20 000 poses of 1k4c: more than one pass of the block-major path holds (19 456 for this complex's 2 808 tile pairs), so
+    the batch runs as two passes, 19 456 + 544, on two streams with two workspace sets -- by the library's own rule, no
     test knob.  Duplicated poses must give the same bits whichever pass evaluates them, and a sample across both passes
     agrees with the oracle."""
     hip, cpu = scorers("1k4c")
@@ -194,17 +194,32 @@ def test_batch_larger_than_one_block_major_pass(pkg, scorers, orc):
     base = case_positions("1k4c", orc)
     n = 20000
     poses = pkg.synth.jitter(base, n, seed=12)
-    poses[n // 2:] = poses[:n // 2]                       # row 10 000 + k repeats row k: 7 408 of them cross the pass boundary
+    poses[n // 2:] = poses[:n // 2]                       # row 10 000 + k repeats row k: 544 of them cross the pass boundary
     e = hip.energy_batch(poses)
     assert np.array_equal(e[:n // 2], e[n // 2:])
     assert np.array_equal(hip.energy_batch(poses[:5]), e[:5])
-    idx = np.concatenate([np.random.default_rng(1).choice(n // 2, size=10, replace=False), [17407, 17408, n - 1]])
+    idx = np.concatenate([np.random.default_rng(1).choice(n // 2, size=10, replace=False), [19455, 19456, n - 1]])
+    assert rel_err(e[idx], cpu.energy_rows(poses[idx])) < REL_TOL
+
+
+def test_pass_of_more_than_65536_rows(pkg, scorers, orc):
+    """70 000 poses of 1ppe are ONE pass of the block-major path (its 104 tile pairs allow 262 144 rows a pass), and a pass of
+    more than 2^16 rows is where the pair kernel keeps an entry's row in 16 + 2 bits (the late steps of a GSO over hundreds of
+    swarms are such launches).  Duplicates on either side of row 65 536 give the same bits; a sample against the oracle."""
+    hip, cpu = scorers("1ppe")
+    assert hip.kernel_info()["pair_kernel_name"] == "dfire_bm_pairs"
+    n = 70000
+    poses = pkg.synth.jitter(case_positions("1ppe", orc), n, seed=21)
+    poses[n // 2:] = poses[:n // 2]                       # row 35 000 + k repeats row k: rows 65 536 .. 69 999 repeat 30 536 .. 34 999
+    e = hip.energy_batch(poses)
+    assert np.array_equal(e[:n // 2], e[n // 2:])
+    idx = np.array([0, 30536, 34999, 65535, 65536, 65537, 69999])
     assert rel_err(e[idx], cpu.energy_rows(poses[idx])) < REL_TOL
 
 
 def test_pass_smaller_than_the_batch_by_construction(pkg, orc, table, tmp_path):
     """A 9 000-atom receptor (141 tiles) against the 3 268-atom ligand of 1k4c (52 tiles): 7 332 tile pairs, for which one
-    pass of the block-major path holds 6 144 poses -- a batch of 8 192 (the bench size) is two passes by construction.
+    pass of the block-major path holds 7 168 poses -- a batch of 8 192 (the bench size) is two passes by construction.
     Against the oracle on a sample, duplicates identical across the passes."""
     import time
     rec = str(tmp_path / "big_rec.pdb")
