@@ -54,6 +54,18 @@ L2_GATHER_CEILING_GBS = 33300.0            # what the L2s deliver to a dense gat
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
+def valu_issue_cost():
+    """Time one wave-level vector instruction of the kind these kernels run (packed f32, conversions, 64-bit integer adds)
+    occupies a SIMD: measured by tools/microbench/valu_rate.hip (8 waves per SIMD, independent copies of v_cvt_u32_f32) and
+    committed as profiles/valu_issue.json together with the shader clock the SIMDs HELD during that loop (s_memtime over
+    s_memrealtime), i.e. the figure in cycles is a measurement, not 'ns x a nominal 2.4 GHz'.  The roof is priced in time."""
+    try:
+        v = json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))
+        return float(v["ns_per_inst"]), v
+    except (OSError, ValueError, KeyError):
+        return 1.86, {"ns_per_inst": 1.86, "source": "profiles/r02_valu_issue_rates.txt (no clock stamp: 4.5 cycles only if the SIMDs hold 2.4 GHz)"}
+
+
 def load_case(name):
     g = os.path.join(GOLD, name)
     if name == "1k4c":
@@ -415,10 +427,12 @@ def main():
         # instruction per ~4.5 cycles per SIMD (profiles/r02_valu_issue_rates.txt); only plain f32 add / mul / fma and
         # bitwise operations go faster.  The instruction-count floor of a launch is what that rate allows.
         binding = None
+        issue_ns, issue_src = valu_issue_cost()
         if prof.get("valu_insts_per_launch"):
-            floor_ms = 1e3 * prof["valu_insts_per_launch"] * 4.5 / (1024 * 2.4e9)
+            floor_ms = 1e-6 * prof["valu_insts_per_launch"] * issue_ns / 1024
             binding = {"what": prof.get("binding", "valu-issue"), "valu_floor_ms": floor_ms, "frac_of_kernel_time": floor_ms / (1e3 * kern_s),
-                       "how": "SQ_INSTS_VALU x 4.5 cycles / (1024 SIMDs x 2.4 GHz)"}
+                       "how": "SQ_INSTS_VALU (profiles/traffic.json) x %.3f ns per wave instruction per SIMD (profiles/valu_issue.json) / 1024 SIMDs" % issue_ns,
+                       "issue_cost": issue_src}
             if prof.get("vmem_insts_per_launch"):
                 binding["tcp_floor_ms"] = 1e3 * prof["vmem_insts_per_launch"] * 17 / (256 * 2.4e9)
         compute = None
@@ -454,12 +468,20 @@ def main():
             lds = {"bound": "LDS pipe busy (SQ_LDS_IDX_ACTIVE per CU)", "frac": busy, "bank_conflict_share": prof.get("lds_bank_conflict_share"),
                    "note": "of the whole sequence's time; the pair kernel alone keeps it busier"}
         if binding:      # what binds: vector issue
-            roof = {"bound": "valu-issue", "achieved": prof["valu_insts_per_launch"] / kern_s / 1e9, "peak": 1024 * 2.4 / 4.5,
+            roof = {"bound": "valu-issue", "achieved": prof["valu_insts_per_launch"] / kern_s / 1e9, "peak": 1024 / issue_ns,
                     "unit": "G wave-instructions/s", "frac": binding["frac_of_kernel_time"]}
         else:            # no counter profile of this build: the byte model, flagged as such
             roof = {"bound": "hbm", "achieved": achieved if hbm_model else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hbm_frac if hbm_model else None, "model_exceeded": bool(hbm_frac > 1.0)}
+        # the two figures SURVEY 8(d) / the tier's rule define, at the top level beside the binding roof: the byte MODEL over the
+        # kernel time, and the HBM traffic the counters saw over the kernel time, both against the 8 TB/s peak
+        roof["frac_survey_8d"] = hbm_frac if (hbm_model is not None) else None
+        roof["hbm_traffic_frac"] = (prof["hbm_bytes_per_launch"] / kern_s / 1e9 / HBM_PEAK_GBS) if prof.get("hbm_bytes_per_launch") else None
         roof.update({"traffic": prof.get("hbm_bytes_per_launch"), "kernel": info["pair_kernel_name"], "kernel_ms": 1e3 * kern_s,
+                     "numerator_source": "`achieved` (valu-issue) = SQ_INSTS_VALU per launch READ FROM profiles/traffic.json (the committed rocprofv3 --pmc pass "
+                                         "of this command, hash-tied to the kernel sources; not re-measured in this run) over the LIVE kernel time (HIP events); "
+                                         "`frac_survey_8d` = SURVEY 8d's algorithmic bytes (P_cut counted live on the GPU) over the live kernel time / 8 TB/s; "
+                                         "`hbm_traffic_frac` = `traffic` (FETCH_SIZE + WRITE_SIZE passes, profiles/traffic.json) over the live kernel time / 8 TB/s",
                      "note": ("`kernel_ms` brackets the whole block-major sequence (memset, dfire_bm_pose, _cull, _plan, _census, _order, _pairs, "
                               "_gather) and `traffic`, `compute`, `binding`, `lds` are sums over it; vector instructions from the committed "
                               "rocprofv3 pass of this command (profiles/), most of them 4.5 cycles per wave on a SIMD; "
@@ -487,8 +509,13 @@ def main():
             cb["cgroup_cpu_quota"] = quota       # None = unlimited; `cores` = the threads run = min(visible, 64, quota)
             out["cpu_baseline"] = cb
             n = min(len(cpu_e), len(energies))
-            # relative, absolute below 1: the DFIRE sums are fixed point (2^-40 of the synthetic table's units), an absolute error model
-            rel = float(np.max(np.abs(energies[:n] - cpu_e[:n]) / np.maximum(np.abs(cpu_e[:n]), 1.0)))
+            diff = np.abs(energies[:n] - cpu_e[:n])
+            if info["pair_kernel_name"].startswith("dfire_bm"):
+                # the block-major path sums table values as 64-bit fixed point (2^-40 of the synthetic table's units, every value
+                # rounded once): an ABSOLUTE error model, |err| <= N_pairs * 2^-41 * 0.0157 (8e-10 for 1k4c in the worst case,
+                # ~4e-12 observed) -- the gate is relative on what exceeds 1e-11
+                diff = np.maximum(diff - 1e-11, 0.0)
+            rel = float(np.max(diff / np.maximum(np.abs(cpu_e[:n]), 1e-9)))
             out["parity_max_rel_err_vs_cpu_sample"] = rel
             if rel > 1e-9:                           # (north_star's tolerance is 1e-4)
                 raise SystemExit("parity violated: %g" % rel)

@@ -146,6 +146,14 @@ int ld_dfire_packed_lut(int cells_per_unit, double ubound, uint32_t *words_out, 
  *                                cutoff inside the cell's interval (hence r = 15.0 exactly, the reference's read past the row, :338)
  * codes_out: 14592 entries. */
 int ld_dfire_bm_lut(double ubound, double lig_extent, uint8_t *codes_out, double *eps_cells_out);
+/* The fixed-point scale of that kernel (host-side, no GPU): table values enter a pose's sum as rint(v * scale), scale =
+ * 2^(44 - e - x), 2^e >= table_vmax, integer adds in any order (the sum src/dfire.rs:325-345 takes in f64).  x makes the sum of
+ * one (pose, ligand tile) -- 64 ligand atoms x the receptor atoms within `reach` = cutoff + the tile's radius of its centre --
+ * fit 63 bits: reach_count_out = an upper bound on the receptor atoms inside ANY ball of that radius (n_rec itself below 8192
+ * atoms: no search), x = extra_bits_out = the bits that count takes beyond 2^13.  scale_out = 0.0: no scale fits (a table
+ * value beyond 1024 or not finite, or a count beyond 2^23) -- such a scorer runs the pose-major kernels. */
+int ld_dfire_bm_fix_scale(const double *rec_xyz /* n_rec x 3 */, size_t n_rec, double reach, double table_vmax,
+                          uint64_t *reach_count_out, int *extra_bits_out, double *scale_out);
 /* The atom order the tiled DFIRE kernel uses (host-side, no GPU): order_out[slot] = original atom
  * index, UINT32_MAX for padding; length = ceil(n/64)*64.  Consecutive 8 slots ("subtile") and 64
  * slots ("tile") are spatially compact; padding only at the tail.  The energy is a plain sum over

@@ -232,6 +232,16 @@ def dfire_bm_lut(ubound=1024.0, lig_extent=45.0):
     return codes, eps.value
 
 
+def dfire_bm_fix_scale(rec_xyz, reach, table_vmax):
+    """(reach count, extra bits, scale) of the block-major kernel's fixed-point sums, see ld_dfire_bm_fix_scale in the header."""
+    xyz = _f64(rec_xyz).reshape(-1, 3)
+    count, extra, scale = C.c_uint64(), C.c_int(), C.c_double()
+    lib = load_library()
+    lib.ld_dfire_bm_fix_scale.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    _check(lib.ld_dfire_bm_fix_scale(_ptr(xyz), xyz.shape[0], C.c_double(reach), C.c_double(table_vmax), C.byref(count), C.byref(extra), C.byref(scale)))
+    return count.value, extra.value, scale.value
+
+
 def spatial_tile_order(xyz):
     """Tile order of the DFIRE kernel: slot -> atom index (UINT32_MAX = padding)."""
     xyz = _f64(xyz).reshape(-1, 3)

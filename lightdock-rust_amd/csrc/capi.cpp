@@ -183,6 +183,18 @@ int ld_dfire_bm_lut(double ubound, double lig_extent, uint8_t *codes_out, double
         if (eps_cells_out) *eps_cells_out = eps;
     });
 }
+int ld_dfire_bm_fix_scale(const double *rec_xyz, size_t n_rec, double reach, double table_vmax, uint64_t *reach_count_out,
+                          int *extra_bits_out, double *scale_out) {
+    return guarded([&] {
+        if ((!rec_xyz && n_rec) || !(reach > 0.0) || !(table_vmax >= 0.0)) throw ld::Error(LD_ERR_INVALID, "coordinates, a positive reach and a non-negative table maximum");
+        const size_t count = ld::dfire_bm_reach_count(rec_xyz, n_rec, reach);
+        int extra = 0;
+        const double scale = ld::dfire_bm_fix_scale(table_vmax, count, &extra);
+        if (reach_count_out) *reach_count_out = (uint64_t)count;
+        if (extra_bits_out) *extra_bits_out = extra;
+        if (scale_out) *scale_out = scale;
+    });
+}
 size_t ld_spatial_tile_order(const double *xyz, size_t n, uint32_t *order_out) {
     size_t len = 0;
     guarded([&] {

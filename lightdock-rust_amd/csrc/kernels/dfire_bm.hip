@@ -560,8 +560,8 @@ struct BmWaveCtx {
     size_t lo;       // first entry of the job
 };
 
-// ---- the exact path.  A flagged cell reads its row's MARKER, (64 + i * 8 + j) << 50, instead of a table value.  After a
-// block's 64 adds the bits above 2^50 of a lane's sum are 0 (no flagged pair), 64 + pair (one: fourteen lanes in a
+// ---- the exact path.  A flagged cell reads its row's MARKER, (64 + i * 8 + j) << kBmMarkerShift (51), instead of a table value.  After a
+// block's 64 adds the bits from 2^51 up of a lane's two sums are 0 (no flagged pair), 64 + pair (one: fourteen lanes in a
 // hundred) or at least 128 (several: four lanes in a thousand).  One flagged pair is named by the sum itself and goes
 // straight into the wave's list of pairs, a 64-bit item = row of the pass | ligand atom << 32 | receptor atom << 48 that
 // needs nothing else of the job it came from: bm_exact_pairs evaluates the list between two jobs, a few hundred pairs at a
@@ -740,6 +740,13 @@ template <bool DEBUG>
 __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
     __shared__ __attribute__((aligned(16))) BmShared S;   // the kernel's only LDS object: at LDS address 0
+    // The batch code (dfire_bm_batch.inc) reads the LUT at `cell` and a cube row at `code + a constant of the instruction`: both
+    // assume S at LDS address 0 with the LUT first.  Another __shared__ object or a different placement would make it read wrong
+    // codes silently: trap instead (the compiler folds the test away when the address is the 0 it assigns today).  The block also
+    // clobbers v220..v255, i.e. it needs the 256 registers of two waves per SIMD.
+    static_assert(offsetof(BmShared, lut) == 0, "the LUT's cell is its LDS address");
+    static_assert(kBmWaves * kBmGroupsPerCu == 8, "dfire_bm_batch.inc clobbers v220..v255: 256 VGPRs a wave = two waves per SIMD");
+    if ((uint32_t)(uintptr_t)&S != 0u) __builtin_trap();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_rt = T->m.rec_n_tiles, n_lt = T->m.lig.n_tiles;

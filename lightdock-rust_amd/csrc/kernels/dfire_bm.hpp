@@ -26,12 +26,16 @@
 //                    [pose][1][2] partials that pose_energy_finish folds (restraint / membrane tail, src/dfire.rs:347-361)
 //
 // Numerics: records are u = fl32(8 (x - c)); the ligand is posed by an f32 affine map whose error
-// is part of `eps`; a LUT cell (1/16 of a unit of 4 d2) whose interval, widened by eps, holds a bin step, the cutoff or
-// distances below 2.5 A (bins 0 and 1, where the interface distance lies) is FLAGGED: its pairs read 0.0 and are
-// recomputed in f64 (exact_pair, dfire_device.hpp) from the f64 coordinates with the reference's quaternion posing.
-// Bins, cutoff decisions and interface flags are therefore the reference's, bit for bit; the energies differ from the
-// other kernels by summation order only, and -- the one liberty this path takes -- the exact path's values reach the
-// pose's sum through a 64-bit fixed-point accumulator (2^-40 units) so that their order cannot matter.
+// is part of `eps`; a LUT cell (1/16 of a unit of 4 d2) whose interval, widened by eps, holds a bin step or the cutoff is
+// FLAGGED: its pairs read the row's MARKER instead of a table value (below) and are recomputed in f64 (the exact path of
+// dfire_bm.hip: f64 coordinates, the reference's quaternion posing and operation order); in a block with an atom that has an
+// interface-flag slot so are the pairs of bins 0 and 1 (r < 2.5 A, where the interface distance lies).  Bins, cutoff decisions
+// and interface flags are therefore the reference's, bit for bit.  The liberty this path takes is the SUM: every table value
+// is rounded ONCE, on the host, to 64-bit fixed point -- rint(v * 2^(44 - e - x)), 2^e >= the table's largest |value|, x = 0
+// unless one ligand tile can reach more than 8191 receptor atoms (scorer.cpp, dfire_bm_fix_scale) -- and a pose's sum is
+// integer adds, exact in any order.  Error model: |error of a pose's sum| <= N_pairs * 2^-(45 - e - x) units of the
+// potential, times the 0.0157 of src/dfire.rs:347 on the energy: 2^-40 units for the synthetic table (e = 4), below 8e-10 on
+// an energy of 1k4c's 114 k pairs in the worst case, 2-4e-12 observed.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -75,8 +79,10 @@ constexpr int kBmWavesPerCu = kBmWaves * kBmGroupsPerCu;
 constexpr int kBmQueuePairs = 8 * kBmPartEntries + 4096 + 512;   // per wave (global memory): 64-bit items, flagged pairs waiting for the exact path: what
                                              // a job can push (one per item), what it may start with, a round of bm_recheck ...
 constexpr int kBmQueueCap = kBmQueuePairs + 8 * kBmPartEntries + 64;   // ... and behind them (entry, block) items whose flagged pairs have to be found again
-constexpr double kBmFixLimit = 2097152.0;    // |table value| the fixed-point sums take (2^21); the scale is 2^(44 - e), 2^e >= the table's largest |value|:
-                                             // 32 pairs of a block stay below 2^49, the 512 of an (entry, ligand subtile) partial below 2^53
+constexpr double kBmFixLimit = 1024.0;       // |table value| the fixed-point sums take; the scale is 2^(44 - e - x), 2^e >= the table's largest |value|:
+                                             // 32 pairs of a block stay below 2^49, the 512 of an (entry, ligand subtile) partial below 2^53, a (row, ligand
+                                             // tile) sum below 2^63 (x, dfire_bm_fix_scale).  At the limit a value still resolves to 2^-34 (6e-11): a table
+                                             // with larger entries (DFIRE's are below 20) runs the pose-major kernels, whose sums are f64
 constexpr int kBmCounters = 8;               // words behind tp_count, zeroed per launch: (tile pair, part) pairs listed, jobs drawn, entries per
                                              // part, jobs listed; behind them kBmCullQueueWords item counters of dfire_bm_cull
 constexpr int kBmCullQueueWords = 256;

@@ -339,22 +339,39 @@ __global__ __launch_bounds__(1024) void gso_movement_phased(const GsoLaunch G) {
 
 }  // namespace
 
-size_t gso_kernel_lds_bytes(const GsoLaunch &g) { return (size_t)6 * g.n_glowworms * sizeof(double); }   // positions, luciferins; the phased kernel's hand-over
+// LDS a workgroup of K2 asks for: the swarm's snapshot (positions, luciferins: 4 doubles a glowworm); the phased kernel keeps its
+// hand-over behind it (the draw, the neighbour count and the chosen neighbour: 2 more).
+size_t gso_kernel_lds_bytes(const GsoLaunch &g, bool phased) { return (size_t)(phased ? 6 : 4) * g.n_glowworms * sizeof(double); }
+
+bool gso_step_is_phased(const GsoLaunch &g) {
+    const bool small = (size_t)g.n_swarms * g.n_glowworms <= 16384;   // (up to 64 swarms of 200 on an MI355X: see gso_movement_phased)
+    const char *mode = std::getenv("LIGHTDOCK_GSO_K2");   // diagnostics / tests: "single" / "phased" whatever the size
+    const std::string m = mode ? mode : "";
+    bool phased = m == "phased" || (m != "single" && small);
+    // a swarm whose snapshot + hand-over do not fit a CU's LDS runs the thread-per-glowworm kernel (4096 glowworms: 128 KiB)
+    if (phased && gso_kernel_lds_bytes(g, true) > kGsoLdsLimit) phased = false;
+    return phased;
+}
 
 hipError_t launch_gso_step(const GsoLaunch &g, hipStream_t stream) {
     if (g.n_swarms == 0) return hipSuccess;
     const int share = (g.n_glowworms + g.parts - 1) / g.parts;
-    const bool small = (size_t)g.n_swarms * g.n_glowworms <= 16384;   // (up to 64 swarms of 200 on an MI355X: see gso_movement_phased)
-    const char *mode = std::getenv("LIGHTDOCK_GSO_K2");   // diagnostics: "single" / "phased" whatever the size
-    const std::string m = mode ? mode : "";
-    if (m == "phased" || (m != "single" && small)) {
+    const bool phased = gso_step_is_phased(g);
+    const size_t lds = gso_kernel_lds_bytes(g, phased);
+    if (lds > kGsoLdsLimit) return hipErrorInvalidValue;   // (gso.cpp admits 4096 glowworms per swarm: 128 KiB)
+    if (lds > 64 * 1024) {   // beyond the default limit of dynamic LDS (N > 2048 single, N > 1365 phased)
+        const hipError_t e = hipFuncSetAttribute(phased ? reinterpret_cast<const void *>(&gso_movement_phased) : reinterpret_cast<const void *>(&gso_movement_phase),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (phased) {
         int pt = (share * kGsoLanes + 63) / 64 * 64;
         pt = pt > 1024 ? 1024 : pt;
-        hipLaunchKernelGGL(gso_movement_phased, dim3((unsigned)(g.n_swarms * g.parts)), dim3((unsigned)pt), gso_kernel_lds_bytes(g), stream, g);
+        hipLaunchKernelGGL(gso_movement_phased, dim3((unsigned)(g.n_swarms * g.parts)), dim3((unsigned)pt), lds, stream, g);
     } else {
         int pt = (share + 63) / 64 * 64;
         pt = pt > 1024 ? 1024 : pt;
-        hipLaunchKernelGGL(gso_movement_phase, dim3((unsigned)(g.n_swarms * g.parts)), dim3((unsigned)pt), gso_kernel_lds_bytes(g), stream, g);
+        hipLaunchKernelGGL(gso_movement_phase, dim3((unsigned)(g.n_swarms * g.parts)), dim3((unsigned)pt), lds, stream, g);
     }
     return hipGetLastError();
 }

@@ -38,7 +38,9 @@ struct GsoLaunch {
     uint32_t *moved_count = nullptr;
 };
 
-size_t gso_kernel_lds_bytes(const GsoLaunch &g);
+constexpr size_t kGsoLdsLimit = 160 * 1024;   // a CU's LDS
+size_t gso_kernel_lds_bytes(const GsoLaunch &g, bool phased);
+bool gso_step_is_phased(const GsoLaunch &g);   // which of the two kernels a launch of this shape runs (LIGHTDOCK_GSO_K2 = single | phased forces one)
 hipError_t launch_gso_step(const GsoLaunch &g, hipStream_t stream);
 
 // rand_core 0.5 SeedableRng::seed_from_u64: PCG32 expansion of a u64 into the ChaCha key

@@ -710,6 +710,83 @@ void Scorer::frame_of_receptor(const ld_molecule &rec, double centre[3], double 
     }
 }
 
+// ---- the fixed-point scale of the block-major path, count-aware.  Table values enter the sums as rint(v * 2^(44 - e - x)),
+// 2^e >= the table's largest |value|.  What has to hold (dfire_bm.hpp): 32 pairs of a block stay below 2^50 (the markers sit at
+// bit 51) -- true for x >= 0 whatever the complex; and a (row, ligand tile) sum, which collects 64 ligand atoms x every receptor
+// atom within the cutoff of any of them, stays below 2^63: 64 K 2^(44 - x) < 2^63 with K = the number of receptor atoms one
+// ligand tile can reach.  K is bounded by geometry: dfire_bm_reach_count() = an upper bound on the receptor atoms inside ANY
+// ball of radius `reach` = cutoff + the largest ligand tile's radius.  x = the bits K takes beyond 2^13 (0 for every real
+// protein: ~3 000 atoms in such a ball).
+size_t dfire_bm_reach_count(const double *xyz, size_t n, double reach) {
+    if (n < 8192) return n;   // cannot overflow whatever the geometry: no search
+    // Any ball of radius `reach` with its centre c in a grid cell of side h lies inside the ball of radius reach + h sqrt(3) / 2
+    // around the cell's centre; centres outside the atoms' bounding box see a subset of what their projection onto it sees.
+    const double h = 4.0, rho = reach + h * 0.8660254037844387, rho2 = rho * rho;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (size_t i = 0; i < n; i++)
+        for (int c = 0; c < 3; c++) {
+            lo[c] = std::min(lo[c], xyz[3 * i + c]);
+            hi[c] = std::max(hi[c], xyz[3 * i + c]);
+        }
+    // the atoms binned in cells of side rho: a probe reads the 27 cells around its own
+    int dim[3];
+    for (int c = 0; c < 3; c++) dim[c] = (int)std::floor((hi[c] - lo[c]) / rho) + 1;
+    if ((double)dim[0] * dim[1] * dim[2] > 1e8) return n;   // (absurdly sparse: give the trivial bound)
+    auto cell_of = [&](const double *p, int *ijk) {
+        for (int c = 0; c < 3; c++) ijk[c] = std::min(dim[c] - 1, std::max(0, (int)std::floor((p[c] - lo[c]) / rho)));
+    };
+    std::vector<uint32_t> start((size_t)dim[0] * dim[1] * dim[2] + 1, 0), order(n);
+    std::vector<uint32_t> cell(n);
+    for (size_t i = 0; i < n; i++) {
+        int ijk[3];
+        cell_of(xyz + 3 * i, ijk);
+        cell[i] = (uint32_t)((ijk[2] * dim[1] + ijk[1]) * dim[0] + ijk[0]);
+        start[cell[i] + 1]++;
+    }
+    for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
+    {
+        std::vector<uint32_t> at(start.begin(), start.end() - 1);
+        for (size_t i = 0; i < n; i++) order[at[cell[i]]++] = (uint32_t)i;
+    }
+    size_t best = 0;
+    int probes[3];
+    for (int c = 0; c < 3; c++) probes[c] = (int)std::floor((hi[c] - lo[c]) / h) + 1;
+    for (int pz = 0; pz < probes[2]; pz++)
+        for (int py = 0; py < probes[1]; py++)
+            for (int px = 0; px < probes[0]; px++) {
+                const double p[3] = {lo[0] + (px + 0.5) * h, lo[1] + (py + 0.5) * h, lo[2] + (pz + 0.5) * h};
+                int ijk[3];
+                cell_of(p, ijk);
+                size_t count = 0;
+                for (int dz = -1; dz <= 1; dz++)
+                    for (int dy = -1; dy <= 1; dy++)
+                        for (int dx = -1; dx <= 1; dx++) {
+                            const int x = ijk[0] + dx, y = ijk[1] + dy, z = ijk[2] + dz;
+                            if (x < 0 || y < 0 || z < 0 || x >= dim[0] || y >= dim[1] || z >= dim[2]) continue;
+                            const size_t k = (size_t)(z * dim[1] + y) * dim[0] + x;
+                            for (uint32_t a = start[k]; a < start[k + 1]; a++) {
+                                const double *q = xyz + 3 * (size_t)order[a];
+                                const double ex = q[0] - p[0], ey = q[1] - p[1], ez = q[2] - p[2];
+                                count += ex * ex + ey * ey + ez * ez <= rho2 ? 1 : 0;
+                            }
+                        }
+                best = std::max(best, count);
+            }
+    return best;
+}
+
+// 2^(44 - e - x); returns 0.0 when no scale fits (a table beyond kBmFixLimit, a non-finite value, or an absurd reach count)
+double dfire_bm_fix_scale(double vmax, size_t reach_count, int *extra_bits_out) {
+    if (!(vmax <= kBmFixLimit)) return 0.0;
+    int e = 0;
+    while (std::ldexp(1.0, e) < std::max(vmax, 1.0)) e++;
+    int x = 0;
+    while (((reach_count + ((size_t)1 << x) - 1) >> x) > 8191) x++;   // 64 K 2^(44 - x) < 2^63  <=>  ceil(K / 2^x) <= 8191
+    if (extra_bits_out) *extra_bits_out = x;
+    if (x > 10) return 0.0;
+    return std::ldexp(1.0, 44 - e - x);
+}
+
 void Scorer::build_bm(const ld_scorer_desc &desc) {
     // rigid molecules only: with ANM the ligand's local coordinates (and the receptor image) change per pose
     if (use_anm_ && (desc.receptor.num_anm > 0 || desc.ligand.num_anm > 0)) return;
@@ -717,10 +794,14 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     const TiledSoA &rec = tiled_rec_soa_, &lig = tiled_lig_soa_;
     if (rec.n_tiles > 1024 || lig.n_tiles > 1024) return;  // an item of the exact path names its atoms in 16 bits each
     if (bm_cull_lds_bytes(rec.n_tiles) + 1024 > kBmLdsPerCu) return;  // the culling kernel keeps every receptor box in LDS: ~430 tiles at most
-    // The exact path's values reach a pose's sum as 2^-40 fixed point (dfire_bm.hpp): a table that could overflow it, or
-    // holds a value the reference would carry as inf / NaN (src/dfire.rs:338), stays with the pose-major kernels.
-    for (size_t i = 0; i < LD_DFIRE_TABLE_LEN; i++)
+    // Table values reach a pose's sum as 64-bit fixed point (dfire_bm.hpp): a table that could overflow it or that the scale
+    // would resolve too coarsely (beyond kBmFixLimit), or one that holds a value the reference would carry as inf / NaN
+    // (src/dfire.rs:338), stays with the pose-major kernels.
+    double table_vmax = 0.0;
+    for (size_t i = 0; i < LD_DFIRE_TABLE_LEN; i++) {
         if (!(std::fabs(desc.potential[i]) <= kBmFixLimit)) return;
+        table_vmax = std::max(table_vmax, std::fabs(desc.potential[i]));
+    }
     double centre[3], half;
     frame_of_receptor(desc.receptor, centre, &half);
     // The frame holds the receptor's box + 16 A: a ligand atom outside it is beyond the cutoff of every receptor atom.
@@ -826,6 +907,7 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
         M.rec_exact = arena_.upload(exact_rows(rec, true));
         // a sphere around every ligand tile (rotation invariant): centre of its box, radius to its farthest atom
         std::vector<float> sphere((size_t)lig.n_tiles * 4, 0.f);
+        bm_tile_radius_.clear();
         for (int t = 0; t < lig.n_tiles; t++) {
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
             for (int i = t * 64; i < t * 64 + 64; i++) {
@@ -846,15 +928,18 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
             }
             for (int k = 0; k < 3; k++) sphere[4 * t + k] = ctr[k];
             sphere[4 * t + 3] = std::nextafter((float)(kBmKappa * r * 1.000001 + 1e-3), INFINITY);
+            bm_tile_radius_.push_back((float)(r * 1.000001 + 1e-3));
         }
         M.lig_tile_sphere = arena_.upload(sphere);
     }
     {   // rows[l][r][b] = potential[r * 3380 + l * 20 + b] in fixed point, b = 0..19; slot 20 = 0, slot 21: the kernel's marker
-        double vmax = 1.0;
-        for (size_t i = 0; i < LD_DFIRE_TABLE_LEN; i++) vmax = std::max(vmax, std::fabs(desc.potential[i]));
-        int e = 0;
-        while (std::ldexp(1.0, e) < vmax) e++;
-        M.fix_scale = std::ldexp(1.0, 44 - e);   // 32 pairs of a block stay below 2^49: under the markers (dfire_bm.hpp)
+        // the scale: 32 pairs of a block stay below 2^49, under the markers, and a (row, ligand tile) sum -- 64 ligand atoms x
+        // the receptor atoms one ligand tile can reach -- inside 63 bits (dfire_bm_fix_scale)
+        double tile_radius = 0.0;   // angstrom: the largest ligand tile's bounding sphere
+        for (int t = 0; t < lig.n_tiles; t++) tile_radius = std::max(tile_radius, (double)bm_tile_radius_[t]);
+        const size_t reach_count = dfire_bm_reach_count(desc.receptor.coordinates, desc.receptor.n_atoms, 15.0 + tile_radius + 0.01);
+        M.fix_scale = dfire_bm_fix_scale(table_vmax, reach_count, nullptr);
+        if (!(M.fix_scale > 0.0)) return;
         std::vector<long long> rows((size_t)kBmTypes * kBmTypes * kBmRowSlots, 0), ones(rows.size(), 0);
         for (uint32_t l = 0; l < (uint32_t)kBmTypes; l++)
             for (uint32_t r = 0; r < (uint32_t)kBmTypes; r++) {
@@ -873,10 +958,14 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     if (tile_pairs * kBmPartEntries * (12 + 8 * kBmJobRows) > ((size_t)16 << 30)) return;   // even the smallest pass (1024 poses) would not fit 16 GiB: the pose-major kernels
     size_t chunk = ((size_t)4 << 30) / ((12 + 8 * kBmJobRows) * tile_pairs);   // a second such workspace exists while two passes are in flight
     chunk = std::min<size_t>(kBmMaxPassPoses, std::max<size_t>(kBmPartEntries, chunk / kBmPartEntries * kBmPartEntries));
-    if (const char *e = std::getenv("LIGHTDOCK_BM_CHUNK")) {
+    if (const char *e = std::getenv("LIGHTDOCK_BM_CHUNK")) {   // tests, A/B: any pass size that the layout can hold --
+        // an entry's index (tile pair * cap + entry) travels in 32 bits (bm_block_item), and the override stays inside the 16 GiB
+        // the default's guard admits for the smallest pass
         const long v = std::atol(e);
-        if (v >= 1) chunk = std::min<size_t>((size_t)v, kBmMaxPassPoses);
+        const size_t by_index = ((size_t)1 << 32) / tile_pairs - 1, by_bytes = ((size_t)16 << 30) / ((12 + 8 * kBmJobRows) * tile_pairs);
+        if (v >= 1) chunk = std::max<size_t>(1, std::min<size_t>({(size_t)v, kBmMaxPassPoses, by_index, by_bytes}));
     }
+    if (tile_pairs * chunk >= ((size_t)1 << 32)) return;   // (unreachable with the 4 GiB default: 76 bytes an entry)
     bm_chunk_ = chunk;
     {
         const char *e = std::getenv("LIGHTDOCK_BM_LANES");

@@ -65,6 +65,8 @@ struct DfireBinning {
 DfireBinning build_dfire_binning();                  // throws if the self-check fails
 double dfire_interface_d2();                         // largest d2 with sqrt(d2)*2-1 <= 3.9
 std::vector<uint32_t> build_packed_lut(int cells_per_unit, double eps, uint32_t zero_bins = 0);  // kPackedLutCells * cells_per_unit words
+size_t dfire_bm_reach_count(const double *xyz, size_t n, double reach);   // upper bound on the atoms inside any ball of that radius (n itself below 8192 atoms)
+double dfire_bm_fix_scale(double vmax, size_t reach_count, int *extra_bits_out);   // the block-major path's fixed-point units per unit of the potential; 0.0: none fits
 std::vector<uint8_t> build_bm_lut(double eps_cells, uint32_t zero_bins = 0);  // kBmLutBytes codes of the block-major kernel (kernels/dfire_bm.hpp)
 
 class Scorer {
@@ -152,6 +154,7 @@ class Scorer {
     BmModel bm_;
     TiledSoA tiled_lig_soa_;
     size_t bm_chunk_ = 0;      // poses per block-major pass (bounds the entry workspace)
+    std::vector<float> bm_tile_radius_;   // angstrom: the ligand tiles' bounding spheres (the reach of the count-aware fixed-point scale)
     size_t bm_pass_poses(size_t n) const;
     size_t bm_sets(size_t n) const;            // workspace sets a batch of n poses needs (2 while two passes are in flight)
     hipStream_t bm_aux_stream_ = nullptr;   // the second of two passes in flight runs here

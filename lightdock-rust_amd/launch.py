@@ -5,7 +5,11 @@ method` process per swarm), done as ONE batched GSO per GPU.
     python lightdock-rust_amd/launch.py <setup.json> <steps> <dfire|dna|pydock> --swarms 0-51 [--init-dir init]
 
 Run it under `python -m torch.distributed.run --nproc-per-node N ...` to shard the swarms over
-N GPUs (rank r takes swarms r, r+N, ...; no collective touches the data path).  Path rules
+N GPUs (rank r takes swarms r, r+N, ...; no collective touches the data path).  Rank -> device: local rank r computes
+on device r.  A launcher that masks the devices PER RANK (SLURM --gpus-per-task, a wrapper exporting
+HIP_VISIBLE_DEVICES=$LOCAL_RANK) must also export LD_RANK_OWNS_DEVICE=1: one visible device next to local rank > 0 is
+otherwise refused (a job-wide mask would put N ranks on one GPU silently).  LIGHTDOCK_DEVICE=<id> pins every rank to one
+device (dry runs of the N-rank path on a 1-GPU box).  Path rules
 follow src/bin/lightdock-rust.rs:158-333: PDBs next to setup.json with the "lightdock_" prefix;
 swarm_<i>/, rec_nm.npy, lig_nm.npy and $LIGHTDOCK_DATA|data/DCparams relative to the CWD.  Where the
 flattened rec_nm.npy / lig_nm.npy (lgd_flatten.py, example/1czy/execution.sh:10-11) are missing, the

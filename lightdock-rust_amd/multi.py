@@ -33,7 +33,7 @@ def device_of_rank(local_rank, visible_devices, forced=None):
     if visible_devices <= 0:
         raise ValueError("no device visible")
     if visible_devices == 1:
-        if local_rank > 0 and not _own_visible_device():
+        if local_rank > 0 and not _own_visible_device(local_rank):
             raise ValueError("local rank %d but one device visible and no per-rank HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES with LD_RANK_OWNS_DEVICE=1" % local_rank)
         return 0
     if local_rank >= visible_devices:
@@ -41,12 +41,15 @@ def device_of_rank(local_rank, visible_devices, forced=None):
     return local_rank
 
 
-def _own_visible_device():
+def _own_visible_device(local_rank=0):
     """One visible device is this rank's OWN only if the launcher says so (LD_RANK_OWNS_DEVICE=1 next to its per-rank
-    HIP_VISIBLE_DEVICES) or the job has one local rank: a visibility variable alone may be job-wide."""
+    HIP_VISIBLE_DEVICES) or the job has one local rank (and this is it: local rank 0): a visibility variable alone may be
+    job-wide.  A launcher that masks devices per rank (SLURM --gpus-per-task, a wrapper script exporting
+    HIP_VISIBLE_DEVICES=$LOCAL_RANK) must export LD_RANK_OWNS_DEVICE=1 too; the repository's own launchers (bench.py's
+    spawn_ranks, torch.distributed.run) leave every device visible and need nothing."""
     import os
     if os.environ.get("LOCAL_WORLD_SIZE", "") == "1":
-        return True
+        return local_rank == 0
     masked = any(os.environ.get(k) not in (None, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
     return masked and os.environ.get("LD_RANK_OWNS_DEVICE") == "1"
 

@@ -498,3 +498,37 @@ def test_committed_profile_matches_the_kernel_sources():
     keys = [k for k in t if k.startswith("1k4c:8192:") and t[k].get("source_hash") == bench.kernel_source_hash()]
     assert keys, "no profiles/traffic.json entry of the default workload carries the hash of the current kernel sources (%s)" % bench.kernel_source_hash()
     assert any(t[k].get("valu_insts_per_launch") for k in keys)
+
+
+def test_block_major_fixed_point_scale_is_count_aware(pkg):
+    """The block-major DFIRE path sums table values as 64-bit fixed point (src/dfire.rs:325-345's sum as integer adds).  A
+    (pose, ligand tile) sum collects 64 ligand atoms x every receptor atom within reach of the tile: 64 K 2^(44 - x) must stay
+    below 2^63, K = the receptor atoms one tile can reach.  The host derives an upper bound on K from the receptor's geometry
+    (dfire_bm_reach_count, for receptors of 8192 atoms and more) and takes bits off the scale when it passes 2^13
+    (the guard used to look at the table's magnitude only)."""
+    rng = np.random.default_rng(5)
+    # below 8192 atoms nothing can overflow: no search, the count is n itself, full scale (2^40 for a table whose largest value is 10)
+    small = rng.uniform(-30, 30, size=(3413, 3))
+    count, extra, scale = pkg.dfire_bm_fix_scale(small, 15.0 + 9.0, 10.0)
+    assert (count, extra, scale) == (3413, 0, 2.0 ** 40)
+    # a protein-like density (one atom per 17 A^3), 20 000 atoms: a ball of radius 24 A holds ~3 400 of them
+    side = (20000 * 17.0) ** (1.0 / 3.0)
+    big = rng.uniform(0, side, size=(20000, 3))
+    count, extra, scale = pkg.dfire_bm_fix_scale(big, 24.0, 10.0)
+    tree_bound = 0
+    from scipy.spatial import cKDTree
+    tree = cKDTree(big)
+    probes = rng.uniform(0, side, size=(4000, 3))
+    tree_bound = max(len(b) for b in tree.query_ball_point(probes, 24.0))
+    assert tree_bound <= count < 8192, (tree_bound, count)        # an upper bound, and a usable one
+    assert extra == 0 and scale == 2.0 ** 40
+    # the same atoms squeezed into a third of the side: one ball holds them all -> 20 000 > 8191 -> two bits off the scale
+    dense = big / 3.0
+    count, extra, scale = pkg.dfire_bm_fix_scale(dense, 24.0, 10.0)
+    assert count == 20000 and extra == 2 and scale == 2.0 ** 38
+    assert 64 * ((count + 3) // 4) * 2 ** 44 < 2 ** 63                # what the two bits buy: the bound of the docstring
+    # the table's own magnitude: 2^e >= vmax; beyond 1024 (or not finite) no scale -- such a scorer runs the pose-major kernels
+    assert pkg.dfire_bm_fix_scale(small, 24.0, 1.0)[2] == 2.0 ** 44
+    assert pkg.dfire_bm_fix_scale(small, 24.0, 1000.0)[2] == 2.0 ** 34
+    assert pkg.dfire_bm_fix_scale(small, 24.0, 2000.0)[2] == 0.0
+    assert pkg.dfire_bm_fix_scale(small, 24.0, float("inf"))[2] == 0.0

@@ -116,6 +116,8 @@ def test_rank_to_device_mapping(pkg, monkeypatch):
     monkeypatch.delenv("LD_RANK_OWNS_DEVICE")
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")            # a job of one local rank
     assert multi.device_of_rank(0, 1) == 0
+    with pytest.raises(ValueError):
+        multi.device_of_rank(1, 1)                       # ... which can only be local rank 0
 
 
 def test_bench_spawns_its_own_ranks(tmp_path):
