@@ -355,7 +355,11 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                     RT_next = more ? base + __ffsll(rtmask) - 1 : RT;
                     rtmask &= rtmask - 1;
                     nb_next = s_sub[RT_next * 8 + bj];
+#ifdef LD_BM_DIAG_NO_TRACKED   // (diagnostic builds: timing only, wrong sums -- no block with a receptor subtile that holds a tracked atom, i.e. 1k4c's beads)
+                    const unsigned long long smask = __ballot(bm_cull_gap2(sub_x, sub_y, sub_z, nb) <= kBmBoxCut && T->m.rec_sub_tracked[RT * 8 + bj] == 0);
+#else
                     const unsigned long long smask = __ballot(bm_cull_gap2(sub_x, sub_y, sub_z, nb) <= kBmBoxCut);  // bit = ligand subtile (lane >> 3) * 8 + receptor subtile
+#endif
                     if (smask) {   // hit `held` of this ballot stays in lane `held` until the ballot's tiles are done
                         held_lo = (uint32_t)bm_writelane((int)(uint32_t)smask, (int)held, (int)held_lo);
                         held_hi = (uint32_t)bm_writelane((int)(uint32_t)(smask >> 32), (int)held, (int)held_hi);
@@ -792,30 +796,42 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         for (int k = 0; k < 4; k++) recf[k] = reinterpret_cast<const float *>(T->m.rec_pairs + (size_t)RT * 32)[k * 64 + lane];
         const TiledBox my_box = T->m.rec_sub[(size_t)RT * 8 + (lane & 7)];           // lane b (mod 8): subtile b's box
         uint32_t any_bits = 0;
-        {   // the job's block masks and rows of the pass: all loads in flight at once
+        {   // the job's block masks and rows of the pass: all loads in flight at once.  UNCONDITIONAL, from two per-lane pointers formed
+            // once: guarded by `e < hi` each of the 32 loads was a basic block of its own -- exec saved, two scalar loads of the
+            // launch arguments and a wait for them, seven scalar instructions of address arithmetic, the load -- 4 of a job set-up's
+            // 8 us.  What the lanes beyond the part's end read (the next part's entries, another tile pair's, never-written
+            // memory: the workspace has a part's room behind its end) is masked out of `bits` and otherwise unused.
             static_assert(kBmPartEntries == 1024, "16 chunks of 64 entries");
+            const unsigned long long *mask_at = T->ent_mask + (tp * T->cap + lo + (size_t)lane);
+            const uint32_t *row_at = T->ent_row + (tp * T->cap + lo + (size_t)lane);
             unsigned long long m[16];
             uint32_t r[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const uint32_t e = lo + (uint32_t)k * 64 + lane;
-                m[k] = e < hi ? T->ent_mask[tp * T->cap + e] : 0ull;
-                r[k] = e < hi ? T->ent_row[tp * T->cap + e] : 0u;
+                m[k] = mask_at[k * 64];
+                r[k] = row_at[k * 64];
             }
+            const uint32_t n_mine = hi - lo;   // entries of the part
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const uint32_t bits = (uint32_t)(m[k] >> (8 * a)) & 0xffu;
+                const uint32_t bits = (uint32_t)(k * 64 + lane) < n_mine ? (uint32_t)(m[k] >> (8 * a)) & 0xffu : 0u;
                 if (k < n_chunks) {
                     WS.row_bits[k * 64 + lane] = (unsigned char)bits;
                     WS.rows[k * 64 + lane] = (unsigned short)r[k];
                 }
-                if (wide_rows) {   // the row's bits 16 and 17, four lanes to a byte
-                    uint32_t hi2 = ((r[k] >> 16) & 3u) << (2 * (lane & 3));
-                    hi2 |= (uint32_t)__shfl_xor((int)hi2, 1, 64);
-                    hi2 |= (uint32_t)__shfl_xor((int)hi2, 2, 64);
-                    if (k < n_chunks && (lane & 3) == 0) WS.rows_hi[(k * 64 + lane) >> 2] = (unsigned char)hi2;
-                }
                 any_bits |= bits;
+            }
+            if (__builtin_expect(wide_rows, 0)) {   // the rows' bits 16 and 17, four lanes to a byte (a pass of more than 2^16 rows: a GSO over hundreds of swarms)
+#pragma unroll 1
+                for (int k = 0; k < n_chunks; k++) {
+                    uint32_t rk = r[0];
+#pragma unroll
+                    for (int u = 1; u < 16; u++) rk = k == u ? r[u] : rk;
+                    uint32_t hi2 = ((rk >> 16) & 3u) << (2 * (lane & 3));
+                    hi2 |= (uint32_t)__builtin_amdgcn_mov_dpp((int)hi2, 0xb1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]: lane ^ 1
+                    hi2 |= (uint32_t)__builtin_amdgcn_mov_dpp((int)hi2, 0x4e, 0xf, 0xf, true);   // quad_perm [2,3,0,1]: lane ^ 2
+                    if ((lane & 3) == 0) WS.rows_hi[(k * 64 + lane) >> 2] = (unsigned char)hi2;
+                }
             }
         }
 #pragma unroll
@@ -837,19 +853,33 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         const bool lig_tracked = T->m.lig_sub_tracked[ls] != 0;
         const uint32_t my_tracked = T->m.rec_sub_tracked[RT * 8 + (lane & 7)];
         const uint32_t lig_rowbase = T->m.lig_rowbase[ls * 8 + (lane & 7)];
-        const size_t row_base = (tp * kBmJobRows + (size_t)a) * T->cap + lo;   // ([tile pair][row][entry]: the batch's lanes write next to each other; with an entry's 8 sums
-                                                                              // together, for the gather's sake, the pair kernel took 200 us longer)
+        // the job's partial sums, one per entry of the part: the wave's own 8 KB of global memory -- written and read again within
+        // microseconds, by this wave only, they never leave the L2 (as a sparse [tile pair][row][entry] array they were 33 M
+        // scattered read-modify-writes of HBM per launch)
+        long long *const my_partial = T->ent_partial + ((size_t)blockIdx.x * kBmWaves + wave) * kBmPartEntries;
         const size_t row_base_entry = tp * T->cap + lo;
+        const uint32_t dma_rowsel = (uint32_t)(lane / kRowPieces) * 4u, dma_piece = (uint32_t)(lane % kRowPieces) * 16u;   // (constants of the lane: row of the five, piece)
         if (DEBUG) dbg_t_scan += now() - dbg_tj;   // job set-up
         // a batch's results, on their way out one batch late (see run_batch)
+        // (the sums' address and stride, opaque to the compiler: read through the kernel arguments at their use they were two scalar
+        // loads and a wait for them inside every batch's write-out)
+        typedef __attribute__((address_space(1))) unsigned long long global_u64;
+        unsigned long long job_tile_sum_bits = (unsigned long long)(uintptr_t)(T->tile_sum + lt);
+        uint32_t job_n_lt = (uint32_t)n_lt;
+        asm volatile("" : "+s"(job_tile_sum_bits), "+s"(job_n_lt));
+        global_u64 *const job_tile_sum = (global_u64 *)job_tile_sum_bits;   // (a GLOBAL pointer: as a generic one the atomic became a flat instruction)
         long long pending_val = 0;
         uint32_t pending_item = 0xffffffffu, pending_row = 0;
+        uint32_t pending_push = 0xffffffffu;       // where in the wave's lists (pairs, then (entry, block) items) the lane's flagged item goes, or none
+        unsigned long long pending_push_item = 0ull;
         auto flush_pending = [&]() {
+            if (pending_push != 0xffffffffu) queue[pending_push] = pending_push_item;
+            pending_push = 0xffffffffu;
             // The (entry, ligand subtile)'s sum is complete with the entry's last block of the job: it goes to the pose's
             // (row, ligand tile) sum by an integer atomic -- order-free, and no gather over 24 M scattered partial sums afterwards.
             if (pending_item != 0xffffffffu) {
-                if (pending_item & 0x4000u) atomicAdd(reinterpret_cast<unsigned long long *>(T->tile_sum + (size_t)pending_row * n_lt + lt), (unsigned long long)pending_val);
-                else T->ent_partial[row_base + (pending_item & 0x3ffu)] = pending_val;
+                if (pending_item & 0x4000u) __hip_atomic_fetch_add(job_tile_sum + (size_t)pending_row * job_n_lt, (unsigned long long)pending_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else my_partial[pending_item & 0x3ffu] = pending_val;
             }
             pending_item = 0xffffffffu;
         };
@@ -858,17 +888,17 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
             const unsigned long long dbg_tblk = now();
             {   // stage the block's rows; they land while the entries are scanned
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous block's reads are done
-                const int dma_row = lane / kRowPieces;                          // (constants of the lane)
-                const uint32_t dma_piece = (uint32_t)(lane % kRowPieces) * 16u;
                 // lane r: where row r = (i, j) = (r / 8, r % 8) of the block starts in the table
                 const uint32_t row_src = (uint32_t)__shfl((int)lig_rowbase, lane >> 3, 64) + (uint32_t)__shfl((int)roff_all, b * 8 + (lane & 7), 64);
-#pragma unroll
-                for (int t = 0; t < kDma; t++) {
-                    const int row = t * kDmaRows + dma_row;
-                    const uint32_t src = (uint32_t)__shfl((int)row_src, row & 63, 64) + dma_piece;
-                    if (lane < kDmaRows * kRowPieces && row < kBmCubeRows)
-                        __builtin_amdgcn_global_load_lds((const global_u32 *)(table_rows + src), (lds_u32 *)(S.cube[wave] + t * (kDmaRows * kBmRowBytes)), 16, 0, 0);
-                }
+                // thirteen copies of five rows: every lane fetches its rows' sources with thirteen ds_bpermute in flight, one wait,
+                // then the copies (LD_BM_DMA_ASM, dfire_bm_batch.inc)
+                static_assert(kDma == 13 && kDmaRows * kBmRowBytes == 880, "LD_BM_DMA_ASM is written for 13 copies of 880 bytes");
+                uint32_t dma_tmp[kDma];
+                unsigned long long dma_exec;
+                const uint32_t cube_lds = (uint32_t)(uintptr_t)S.cube[wave];
+#ifndef LD_BM_DIAG_NO_DMA   // (diagnostic builds: timing only, wrong sums)
+                LD_BM_DMA_ASM(dma_exec, dma_tmp, dma_rowsel, row_src, dma_piece, table_rows, cube_lds, 0x007fffffffffffffull, 0x00000fffffffffffull);
+#endif
             }
             const bool tracked = lig_tracked || __builtin_amdgcn_readlane((int)my_tracked, b) != 0;
             constexpr float seed = (float)kBmCellZero + 0.5f;
@@ -912,7 +942,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 L.a1 = ap[1];
                 L.a2 = ap[2];
                 L.prev = 0;
-                if (!(L.item & 0x8000u)) L.prev = T->ent_partial[row_base + el];
+                if (!(L.item & 0x8000u)) L.prev = my_partial[el];
                 return L;
             };
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the item list as every lane wrote it
@@ -930,17 +960,23 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
             const float cby = 0.5f * (lane_f32(my_box.loy, b) + lane_f32(my_box.hiy, b));
             const float cbz = 0.5f * (lane_f32(my_box.loz, b) + lane_f32(my_box.hiz, b));
             const float rec_here = (b >> 1) == 0 ? recf[0] : (b >> 1) == 1 ? recf[1] : (b >> 1) == 2 ? recf[2] : recf[3];
+            // The sixteen operands end up in SCALAR register pairs (v_readfirstlane of the wave-uniform results: gfx950 has no scalar
+            // float unit), once per block: held in vector registers the compiler re-derived all of them from the records in every
+            // batch instead.
             v2f Rx[4], Ry[4], Rz[4], Rs[4];   // 2 (r - c), and seed - |r - c|^2
+            auto uniform = [](v2f v) {
+                return v2f{__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.x))), __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.y)))};
+            };
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int at = (b & 1) * 32 + q * 8;   // record q of the subtile: x0 x1 y0 y1 z0 z1 . .
                 const v2f x = v2f{lane_f32(rec_here, at), lane_f32(rec_here, at + 1)} - v2f{cbx, cbx};
                 const v2f y = v2f{lane_f32(rec_here, at + 2), lane_f32(rec_here, at + 3)} - v2f{cby, cby};
                 const v2f z = v2f{lane_f32(rec_here, at + 4), lane_f32(rec_here, at + 5)} - v2f{cbz, cbz};
-                Rs[q] = __builtin_elementwise_fma(-x, x, __builtin_elementwise_fma(-y, y, __builtin_elementwise_fma(-z, z, v2f{seed, seed})));
-                Rx[q] = x * v2f{2.f, 2.f};
-                Ry[q] = y * v2f{2.f, 2.f};
-                Rz[q] = z * v2f{2.f, 2.f};
+                Rs[q] = uniform(__builtin_elementwise_fma(-x, x, __builtin_elementwise_fma(-y, y, __builtin_elementwise_fma(-z, z, v2f{seed, seed}))));
+                Rx[q] = uniform(x * v2f{2.f, 2.f});
+                Ry[q] = uniform(y * v2f{2.f, 2.f});
+                Rz[q] = uniform(z * v2f{2.f, 2.f});
             }
             if (DEBUG) dbg_t_block += now() - dbg_tblk;   // block set-up
 
@@ -974,16 +1010,20 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 const bool any_flagged = valid && mark != 0;
                 const bool one = any_flagged && (mark0 == 0 || mark1 == 0) && mark >= 64 && mark < 128, several = any_flagged && !one;
                 const unsigned long long m1 = __ballot(one), m2 = __ballot(several);
-                if (one) {   // the lane's one pair in a flagged cell (0.1 % of all pairs): the exact path
-                    const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+                // the lane's one pair in a flagged cell (0.1 % of all pairs; some lane of nearly every batch has one): the exact path.
+                // Like the lane's sum, the item leaves at the start of the NEXT batch (flush_pending): stored here, just before the
+                // loop's wait for the next batch's loads, that wait was for this store's acknowledgement -- in every batch.
+                pending_push = 0xffffffffu;
+                if (one) {
                     const int pair = (int)mark - 64;
-                    queue[at] = bm_pair_item(cur.row, ls * 8 + (pair >> 3), RT * 64 + b * 8 + (pair & 7));
+                    pending_push = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+                    pending_push_item = bm_pair_item(cur.row, ls * 8 + (pair >> 3), RT * 64 + b * 8 + (pair & 7));
                 }
                 queued += (uint32_t)__popcll(m1);
                 if (__builtin_expect(m2 != 0ull, 0)) {
-                    if (several) {
-                        const uint32_t at = queued_blocks + __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
-                        queue_blocks[at] = bm_block_item(row_base_entry + el, a, b);
+                    if (several) {   // (a lane has one flagged pair or several, never both: one slot serves both lists -- queue_blocks = queue + kBmQueuePairs)
+                        pending_push = (uint32_t)kBmQueuePairs + queued_blocks + __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+                        pending_push_item = bm_block_item(row_base_entry + el, a, b);
                     }
                     queued_blocks += (uint32_t)__popcll(m2);
                 }
@@ -997,7 +1037,15 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
             for (uint32_t done = 0; done < n_items; done += 64) {
                 if (DEBUG) dbg_batches++;
                 const unsigned long long dbg_tb = now();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this batch's loads (and, the first time, the block's rows) are in
+                // this batch's loads are in (the compiler's own count: behind them only the previous batch's push into the wave's
+                // list may still be in flight); the first time also the block's rows, which the compiler does not know it waits for
+                if (done == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (the empty statement READS what the loads return: the compiler's wait for them goes here, in front of the writes
+                // and loads issued below, counted exactly.  Without it the wait sat at the values' first use, behind the next
+                // batch's loads, as `vmcnt(3)` -- the count of the shortest path -- which on the usual path, four loads and
+                // a write or two, waited for the first of the loads just issued: a round trip to the L2 in every batch.)
+                asm volatile("" :: "v"(next.a0.x), "v"(next.a0.y), "v"(next.a0.z), "v"(next.a0.w), "v"(next.a1.x), "v"(next.a1.y), "v"(next.a1.z), "v"(next.a1.w),
+                             "v"(next.a2.x), "v"(next.a2.y), "v"(next.a2.z), "v"(next.a2.w), "v"(next.prev));
                 const BatchLoads cur = next;
                 flush_pending();   // (in front of the next batch's loads)
                 // the rows' markers, over what the copy left in their slots (they name the PAIR: not part of the table); in a block
@@ -1021,6 +1069,9 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                     default: run_batch(std::integral_constant<int, 3>{}, cur, done); break;
                 }
                 if (DEBUG) dbg_t_batch += now() - dbg_tb;
+#ifdef LD_BM_DIAG_FIRST   // (diagnostic builds: the drain timer holds the time of every block's FIRST batch -- the wait for the rows and the first loads)
+                if (DEBUG && done == 0) dbg_t_drain += now() - dbg_tb;
+#endif
             }
             flush_pending();   // (the next block's first loads read what this block's last batch wrote)
         }

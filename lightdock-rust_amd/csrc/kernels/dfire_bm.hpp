@@ -162,7 +162,8 @@ struct BmLaunch {
     uint32_t *tp_count = nullptr;          // [n_tile_pairs], zeroed per launch
     uint32_t *ent_row = nullptr;           // [tile pair][cap]
     unsigned long long *ent_mask = nullptr;  // [tile pair][cap]
-    long long *ent_partial = nullptr;      // [tile pair][kBmJobRows][cap], fixed point
+    long long *ent_partial = nullptr;      // [wave of dfire_bm_pairs][kBmPartEntries], fixed point: the partial sums of the wave's CURRENT job, one per entry of the
+                                           // part (8 KB a wave that never leave the L2; until round 5 a sparse [tile pair][8][cap] array: 33 M scattered HBM read-modify-writes a launch)
     uint32_t *jobs = nullptr;              // [(tile pair, part)][2]: tile pair, first entry; written by dfire_bm_plan
     uint32_t *job_count = nullptr;         // [kBmCounters], zeroed per launch: (tile pair, part) pairs listed, jobs drawn (job_next = job_count + 1),
                                            // entries per part, jobs listed in job_order

@@ -953,19 +953,21 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
         M.rows = arena_.upload(rows);
         M.rows_ones = arena_.upload(ones);
     }
-    // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x (12 + 8 per job row) bytes
+    // poses per pass: the entry workspace is (tile pairs) x (poses of the pass) x 12 bytes (an entry's row and block mask; until
+    // round 5 also 64 bytes of partial sums per entry, which now live in a per-wave scratch: the budgets kept their pass sizes)
     const size_t tile_pairs = (size_t)rec.n_tiles * lig.n_tiles;
-    if (tile_pairs * kBmPartEntries * (12 + 8 * kBmJobRows) > ((size_t)16 << 30)) return;   // even the smallest pass (1024 poses) would not fit 16 GiB: the pose-major kernels
-    size_t chunk = ((size_t)4 << 30) / ((12 + 8 * kBmJobRows) * tile_pairs);   // a second such workspace exists while two passes are in flight
+    constexpr size_t kEntryBytes = 12;
+    if (tile_pairs * kBmPartEntries * kEntryBytes > ((size_t)2560 << 20)) return;   // even the smallest pass (1024 poses) would not fit 2.5 GiB: the pose-major kernels
+    size_t chunk = ((size_t)640 << 20) / (kEntryBytes * tile_pairs);   // a second such workspace exists while two passes are in flight
     chunk = std::min<size_t>(kBmMaxPassPoses, std::max<size_t>(kBmPartEntries, chunk / kBmPartEntries * kBmPartEntries));
     if (const char *e = std::getenv("LIGHTDOCK_BM_CHUNK")) {   // tests, A/B: any pass size that the layout can hold --
         // an entry's index (tile pair * cap + entry) travels in 32 bits (bm_block_item), and the override stays inside the 16 GiB
         // the default's guard admits for the smallest pass
         const long v = std::atol(e);
-        const size_t by_index = ((size_t)1 << 32) / tile_pairs - 1, by_bytes = ((size_t)16 << 30) / ((12 + 8 * kBmJobRows) * tile_pairs);
+        const size_t by_index = ((size_t)1 << 32) / tile_pairs - 1, by_bytes = ((size_t)2560 << 20) / (kEntryBytes * tile_pairs);
         if (v >= 1) chunk = std::max<size_t>(1, std::min<size_t>({(size_t)v, kBmMaxPassPoses, by_index, by_bytes}));
     }
-    if (tile_pairs * chunk >= ((size_t)1 << 32)) return;   // (unreachable with the 4 GiB default: 76 bytes an entry)
+    if (tile_pairs * chunk >= ((size_t)1 << 32)) return;   // (unreachable with the 640 MiB default: 12 bytes an entry)
     bm_chunk_ = chunk;
     {
         const char *e = std::getenv("LIGHTDOCK_BM_LANES");
@@ -1041,7 +1043,7 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         t.queue = static_cast<unsigned long long *>(ws_bm_queue_.ptr) + w * waves * kBmQueueCap;
         t.ent_row = static_cast<uint32_t *>(ws_bm_ent_row_.ptr) + w * tile_pairs * cap;
         t.ent_mask = static_cast<unsigned long long *>(ws_bm_ent_mask_.ptr) + w * tile_pairs * cap;
-        t.ent_partial = static_cast<long long *>(ws_bm_ent_partial_.ptr) + w * tile_pairs * kBmJobRows * cap;
+        t.ent_partial = static_cast<long long *>(ws_bm_ent_partial_.ptr) + w * waves * kBmPartEntries;
         t.tile_sum = static_cast<long long *>(ws_bm_tile_sum_.ptr) + w * cap * n_lt;
         t.exact_fix = static_cast<long long *>(ws_bm_exact_fix_.ptr) + w * cap;
         // With pair counts wanted the sequence runs twice: first as a counting launch (the same kernels over rows of ones and the
@@ -1173,9 +1175,10 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         ws_bm_job_cost_.reserve(sets * parts * kBmJobRows * sizeof(uint32_t));
         ws_bm_job_order_.reserve(sets * parts * kBmJobRows * sizeof(uint32_t));
         ws_bm_queue_.reserve(sets * waves * kBmQueueCap * sizeof(unsigned long long));
-        ws_bm_ent_row_.reserve(sets * tile_pairs * cap * sizeof(uint32_t));
-        ws_bm_ent_mask_.reserve(sets * tile_pairs * cap * sizeof(unsigned long long));
-        ws_bm_ent_partial_.reserve(sets * tile_pairs * kBmJobRows * cap * sizeof(long long));
+        // (+ one part: a job of dfire_bm_pairs loads its part's 1024 entries without looking at the part's end; what lies beyond is never used)
+        ws_bm_ent_row_.reserve((sets * tile_pairs * cap + kBmPartEntries) * sizeof(uint32_t));
+        ws_bm_ent_mask_.reserve((sets * tile_pairs * cap + kBmPartEntries) * sizeof(unsigned long long));
+        ws_bm_ent_partial_.reserve(sets * waves * kBmPartEntries * sizeof(long long));   // per wave of dfire_bm_pairs: the partial sums of its current job (8 KB, L2 resident)
         ws_bm_tile_sum_.reserve(sets * cap * n_lt * sizeof(long long));
         ws_bm_exact_fix_.reserve(sets * cap * sizeof(long long));
         if (counts) {

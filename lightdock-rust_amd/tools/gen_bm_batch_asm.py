@@ -16,7 +16,7 @@ issues, scalar or wait, costs it a turn.
 
 Temporaries are fixed registers (clobbered): v[220:235] table values, v[236:243] / v[244:251]
 cells and codes, v[252:255] the two packed E.  Operands: acc, acc1 (+v, 64 bit: the sums over the pairs with the even / odd receptor atom of a record), Rs0..3 Rz0..3 Ry0..3 Rx0..3 (the block's receptor
-records, wave-uniform), l2/lz/ly/lx0..3 = the values of the lane's ligand atoms (2p, 2p + 1), cube = LDS address of the wave's cube.
+records, wave-uniform: scalar register pairs), l2/lz/ly/lx0..3 = the values of the lane's ligand atoms (2p, 2p + 1), cube = LDS address of the wave's cube.
 """
 import os
 
@@ -87,6 +87,32 @@ def pose_block():
     return lines, outs, ins
 
 
+def dma_block():
+    """A block's 64 table rows L2 -> LDS: 13 LDS-DMA instructions of five rows each (55 lanes: row of the five, one of the row's
+    11 pieces of 16 bytes).  Lane r of SRC holds the table offset of row r; the lane that copies (row, piece) of instruction t
+    fetches it with ds_bpermute -- ALL THIRTEEN in flight, one wait, then the thirteen copies.  (Written as a loop in C++ the
+    compiler made thirteen rounds of bpermute / s_waitcnt lgkmcnt(0) / copy, each a full LDS latency: 1.7 of a block set-up's
+    2.5 us.)  Operands: ROWSEL = 4 * (row of the five), PIECE = 16 * piece (constants of the lane), SRC, TABLE (64-bit, uniform:
+    the row table), CUBE (uniform: the LDS address of the wave's cube), M55 / M44 (the lanes of an instruction: 55, the last
+    one's 44 -- its fifth row would be row 64).  Clobbers m0."""
+    # (the bpermutes with every lane active: a lane that is switched off pushes nothing, and reading it returns 0)
+    lines = []
+    for t in range(13):
+        lines.append("ds_bpermute_b32 %%[t%d], %%[rowsel], %%[src] offset:%d" % (t, 20 * t))
+    lines += ["s_mov_b64 %[save], exec", "s_mov_b64 exec, %[m55]", "s_waitcnt lgkmcnt(0)"]
+    for t in range(13):
+        if t == 12:
+            lines.append("s_mov_b64 exec, %[m44]")
+        lines.append("v_add_u32 %%[t%d], %%[t%d], %%[piece]" % (t, t))
+        lines.append("s_add_u32 m0, %%[cube], %d" % (880 * t))
+        lines.append("s_nop 0")
+        lines.append("global_load_lds_dwordx4 %%[t%d], %%[table]" % t)
+    lines.append("s_mov_b64 exec, %[save]")
+    outs = ['[save] "=&s"(SAVE)'] + ['[t%d] "=&v"(TMP[%d])' % (t, t) for t in range(13)]
+    ins = ['[rowsel] "v"(ROWSEL)', '[src] "v"(SRC)', '[piece] "v"(PIECE)', '[table] "s"(TABLE)', '[cube] "s"(CUBE)', '[m55] "s"(M55)', '[m44] "s"(M44)']
+    return lines, outs, ins
+
+
 def main():
     lines = []
     for h in range(10):
@@ -101,7 +127,10 @@ def main():
     body = " \\\n".join('    "%s\\n\\t"' % l for l in lines)
     ops_in = []
     for name in ("rs", "rz", "ry", "rx"):
-        ops_in += ['[%s%d] "v"(%s[%d])' % (name, g, {"rs": "Rs", "rz": "Rz", "ry": "Ry", "rx": "Rx"}[name], g) for g in range(4)]
+        # the block's receptor operands are wave-uniform: SCALAR register pairs (a packed instruction takes one as its first source).
+        # As vector registers the compiler kept the raw records in scalar registers and RECOMPUTED all sixteen operands in every
+        # batch (36 packed instructions + the box centre: a ninth of a batch's vector instructions) rather than hold 32 registers.
+        ops_in += ['[%s%d] "s"(%s[%d])' % (name, g, {"rs": "Rs", "rz": "Rz", "ry": "Ry", "rx": "Rx"}[name], g) for g in range(4)]
     for name, arr in (("l2", "L2"), ("lz", "LZ"), ("ly", "LY"), ("lx", "LX")):
         ops_in += ['[%s%d] "v"(%s[%d])' % (name, p, arr, p) for p in range(4)]
     clobbers = ", ".join('"v%d"' % r for r in range(220, 256))
@@ -118,6 +147,11 @@ def main():
         f.write("#define LD_BM_POSE_ASM(LX, LY, LZ, L2, A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, X, Y, Z) \\\n  asm( \\\n")
         f.write(" \\\n".join('    "%s\\n\\t"' % l for l in plines) + " \\\n")
         f.write("    : " + ", \\\n      ".join(pouts) + " \\\n    : " + ", \\\n      ".join(pins) + ")\n")
+        dlines, douts, dins = dma_block()
+        f.write("\n// a block's 64 table rows -> the wave's cube: 13 ds_bpermute in flight, one wait, 13 LDS-DMA copies\n")
+        f.write("#define LD_BM_DMA_ASM(SAVE, TMP, ROWSEL, SRC, PIECE, TABLE, CUBE, M55, M44) \\\n  asm volatile( \\\n")
+        f.write(" \\\n".join('    "%s\\n\\t"' % l for l in dlines) + " \\\n")
+        f.write("    : " + ", \\\n      ".join(douts) + " \\\n    : " + ", \\\n      ".join(dins) + ' \\\n    : "memory")\n')
     print("wrote", os.path.normpath(path), len(lines), "+", len(plines), "instructions")
 
 

@@ -65,9 +65,11 @@ double run(const char *name, double base) {
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     const double per = ms * 1e-3 / ((double)iters * 16 * 8);  // seconds per instruction per SIMD
     unsigned long long h[2]; CHECK(hipMemcpy(h, stamps, 16, hipMemcpyDeviceToHost));
-    // one wave's loop: `h[0]` shader-clock ticks in `h[1]` ticks of 10 ns; its SIMD ran 8 such waves, i.e. iters * 16 * 8 instructions
+    // one wave's loop: `h[0]` shader-clock ticks in `h[1]` ticks of 10 ns -- the clock that wave's SIMD held; the cost of an
+    // instruction in cycles = its time per SIMD (events around the whole launch: independent of how many waves were resident
+    // at once) x that clock
     const double ghz = h[1] ? (double)h[0] / ((double)h[1] * 10.0) : 0.0;
-    const double cycles = (double)h[0] / ((double)iters * 16 * 8);
+    const double cycles = per * 1e9 * ghz;
     std::printf("%-28s %8.3f ms  %6.2f ns/instr/SIMD  x%.2f of v_add_f32   shader clock %.3f GHz  %5.2f cycles/instr/SIMD (s_memtime)\n", name, ms, per * 1e9,
                 base > 0 ? per / base : 1.0, ghz, cycles);
     g_last = Result{per * 1e9, cycles, ghz};
