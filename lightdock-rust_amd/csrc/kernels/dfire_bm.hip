@@ -546,7 +546,6 @@ struct BmWaveShared {
     unsigned short items[kBmPartEntries];          // the entries that hold the current block (| 0x8000: its first block of the row)
     unsigned short rows[kBmPartEntries];           // per entry of the job: its row of the pass (where its affine map is), bits 0..15
     unsigned char rows_hi[kBmPartEntries / 4];     // ... and bits 16, 17: four entries to a byte (a pass holds up to 2^18 rows)
-    alignas(16) float lig_local[3][8];                         // the job's ligand atoms: local x of the eight, y, z (read back as pairs of atoms)
 };
 struct BmShared {
     unsigned char lut[kBmLutBytes];   // indexed from the far end: cell' = floor(kBmCellZero + 1/2 - 64 d2), everything further reads cell' 0
@@ -791,10 +790,6 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         // What the job's blocks need that does not depend on the entry, for all 8 receptor subtiles of the tile at once (one
         // latency, together with the masks): lane = (receptor subtile b, atom j).
         const uint32_t roff_all = T->m.rec_rowoff[(size_t)RT * 64 + lane];           // the atom's column in a table row block
-        float recf[4];                                                                // the tile's 32 pair records, 256 floats
-#pragma unroll
-        for (int k = 0; k < 4; k++) recf[k] = reinterpret_cast<const float *>(T->m.rec_pairs + (size_t)RT * 32)[k * 64 + lane];
-        const TiledBox my_box = T->m.rec_sub[(size_t)RT * 8 + (lane & 7)];           // lane b (mod 8): subtile b's box
         uint32_t any_bits = 0;
         {   // the job's block masks and rows of the pass: all loads in flight at once.  UNCONDITIONAL, from two per-lane pointers formed
             // once: guarded by `e < hi` each of the 32 loads was a basic block of its own -- exec saved, two scalar loads of the
@@ -843,7 +838,19 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         // the ligand subtile's local coordinates (uniform)
         // (kept in LDS, read back per batch as broadcasts: 24 wave-uniform values in vector registers for the whole job are what
         // pushed the block set-up into scratch)
-        if (lane < 24) WS.lig_local[lane >> 3][lane & 7] = T->m.lig_local[(size_t)(ls * 8 + (lane & 7)) * 4 + (lane >> 3)];
+        // (in SCALAR registers, two atoms a pair -- the operands of the packed posing instructions.  Kept in LDS and read back per batch
+        // they cost every batch an LDS round trip at its head; 24 wave-uniform values in vector registers pushed the block set-up into scratch.)
+        v2f LocX[4], LocY[4], LocZ[4];
+        {
+            const float mine = T->m.lig_local[(size_t)(ls * 8 + (lane & 7)) * 4 + (lane < 24 ? lane >> 3 : 0)];   // lanes 0..7 x, 8..15 y, 16..23 z
+            auto from = [&](int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), l)); };
+#pragma unroll
+            for (int p2 = 0; p2 < 4; p2++) {
+                LocX[p2] = v2f{from(2 * p2), from(2 * p2 + 1)};
+                LocY[p2] = v2f{from(8 + 2 * p2), from(9 + 2 * p2)};
+                LocZ[p2] = v2f{from(16 + 2 * p2), from(17 + 2 * p2)};
+            }
+        }
         // table rows of a block -> LDS by LDS-DMA: an instruction copies 5 rows, lane = (row of the five, one of its 11 pieces of
         // 16 bytes) -- the lane's two numbers are the same for every instruction, 55 lanes take part (piece p of an instruction
         // lands at its LDS address + 16 p: five rows of 176 bytes, contiguous).  The lane keeps the row block of ligand atom
@@ -878,8 +885,15 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
             // The (entry, ligand subtile)'s sum is complete with the entry's last block of the job: it goes to the pose's
             // (row, ligand tile) sum by an integer atomic -- order-free, and no gather over 24 M scattered partial sums afterwards.
             if (pending_item != 0xffffffffu) {
+                // (LD_BM_DIAG_*: diagnostic builds -- timing only, wrong sums: what the kernel takes without one of its memory streams)
+#ifndef LD_BM_DIAG_NO_ATOMIC
                 if (pending_item & 0x4000u) __hip_atomic_fetch_add(job_tile_sum + (size_t)pending_row * job_n_lt, (unsigned long long)pending_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+                if (pending_item & 0x4000u) asm volatile("" :: "v"(pending_val), "v"(pending_row));
+#endif
+#ifndef LD_BM_DIAG_NO_PARTIAL
                 else my_partial[pending_item & 0x3ffu] = pending_val;
+#endif
             }
             pending_item = 0xffffffffu;
         };
@@ -901,7 +915,6 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
 #endif
             }
             const bool tracked = lig_tracked || __builtin_amdgcn_readlane((int)my_tracked, b) != 0;
-            constexpr float seed = (float)kBmCellZero + 0.5f;
             // ---- the job's entries that hold block (a, b), in entry order (all 16 chunks' bytes in flight, then the ballots)
             uint32_t n_items = 0;
             {
@@ -913,11 +926,9 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                     const uint32_t bits = bits16[k];
                     const bool act = (bits >> b) & 1u;
                     const unsigned long long m = __ballot(act);
-                    if (act) {
+                    if (act) {   // (the entry's number only: whether this is its first or last block of the job is worked out per batch, read_row)
                         const uint32_t at = n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        const bool first = (bits & ((1u << b) - 1u)) == 0u;   // the entry's first block of this job: nothing to add to yet
-                        const bool last = (bits >> (b + 1)) == 0u;             // ... its last: the (entry, row)'s sum is complete
-                        WS.items[at] = (unsigned short)((uint32_t)(k * 64 + lane) | (first ? 0x8000u : 0u) | (last ? 0x4000u : 0u));
+                        WS.items[at] = (unsigned short)(k * 64 + lane);
                     }
                     n_items += (uint32_t)__popcll(m);
                 }
@@ -929,24 +940,58 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 long long prev;      // the entry's partial of this row so far
                 uint32_t item, row;
             };
-            auto issue_loads = [&](uint32_t first_item) {
-                BatchLoads L;
+            // The way from a batch's place in the item list to its loads goes through LDS twice -- the item, then the entry's row of
+            // the pass --: looked up when the loads were due, that was two LDS round trips at the head of every batch, with the
+            // other wave of the SIMD keeping the LDS queue full.  They run AHEAD now: while batch k is walked, the loads of batch
+            // k + 1 are in flight (issued from a row that is already in a register), the row of batch k + 2 and the item of
+            // batch k + 3 are being read -- behind the batch's own LDS traffic, whose last wait covers them.
+            auto first_of = [&](uint32_t first_item) { return first_item < n_items ? first_item : 0u; };   // (beyond the block's end: its first items again)
+            auto read_item = [&](uint32_t first_item) {
                 const uint32_t at = first_item + (uint32_t)lane;
-                L.item = WS.items[at < n_items ? at : first_item];
-                const uint32_t el = L.item & 0x3ffu;
+                return (uint32_t)WS.items[at < n_items ? at : first_item];
+            };
+            // the entry's row of the pass, and in bits 30 / 31 of the same word whether block b is the entry's LAST / FIRST of this job
+            // (last: the (entry, row)'s sum is complete; first: nothing to add to yet) -- from the entry's byte of block bits
+            auto read_row = [&](uint32_t item) {
+                const uint32_t el = item & 0x3ffu;
                 uint32_t row = (uint32_t)WS.rows[el];
+                const uint32_t bits = (uint32_t)WS.row_bits[el];
                 if (wide_rows) row |= (((uint32_t)WS.rows_hi[el >> 2] >> (2 * (el & 3))) & 3u) << 16;
+                // (x - 1) has bit 31 set exactly when x = 0, for x below 2^31
+                row |= ((bits & ((1u << b) - 1u)) - 1u) & 0x80000000u;
+                row |= (((bits >> (b + 1)) - 1u) >> 1) & 0x40000000u;
+                return row;
+            };
+            auto issue_loads = [&](uint32_t item_el, uint32_t row_and_flags) {
+                BatchLoads L;
+                const uint32_t item = (item_el & 0x3ffu) | (row_and_flags >> 16 & 0xc000u);   // entry | first << 15 | last << 14, as the code below reads it
+                const uint32_t row = row_and_flags & 0x3ffffu;
+                L.item = item;
                 L.row = row;
+#ifndef LD_BM_DIAG_ROW_OF_LANE
                 const float4 *ap = reinterpret_cast<const float4 *>(T->rt) + (size_t)row * 3;
+#else
+                const float4 *ap = reinterpret_cast<const float4 *>(T->rt) + (size_t)(row & 63u) * 3;   // (every load from the same 3 KB)
+#endif
                 L.a0 = ap[0];
                 L.a1 = ap[1];
                 L.a2 = ap[2];
                 L.prev = 0;
-                if (!(L.item & 0x8000u)) L.prev = my_partial[el];
+#ifndef LD_BM_DIAG_NO_PARTIAL
+                if (!(item & 0x8000u)) L.prev = my_partial[item & 0x3ffu];
+#endif
                 return L;
             };
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the item list as every lane wrote it
-            BatchLoads next = issue_loads(0);
+            uint32_t look_item, look_row, look2_item;   // batch 1's item and row, batch 2's item
+            BatchLoads next;
+            {
+                const uint32_t item0 = read_item(0u);
+                look_item = read_item(first_of(64u));
+                look2_item = read_item(first_of(128u));
+                next = issue_loads(item0, read_row(item0));
+                look_row = read_row(look_item);
+            }
             // (behind the first batch's loads: their latency covers it)
             // receptor subtile b of the tile: 4 pair records, wave-uniform, out of the registers loaded at the job's start
             // The block's distance arithmetic has its origin at the centre c of the receptor subtile's box:
@@ -955,29 +1000,22 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
             // enough (below 2^17 for every pair within reach of the cutoff) that the roundings stay inside eps.  The LUT
             // is indexed from the far end: a pair beyond its last cell has E < 0, which v_cvt_u32_f32 turns into cell' 0
             // ("miss") like a NaN -- no clamp.  (bm_drain repeats this arithmetic: keep the two in step.)
-            auto lane_f32 = [](float v, int from) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), from)); };
-            const float cbx = 0.5f * (lane_f32(my_box.lox, b) + lane_f32(my_box.hix, b));
-            const float cby = 0.5f * (lane_f32(my_box.loy, b) + lane_f32(my_box.hiy, b));
-            const float cbz = 0.5f * (lane_f32(my_box.loz, b) + lane_f32(my_box.hiz, b));
-            const float rec_here = (b >> 1) == 0 ? recf[0] : (b >> 1) == 1 ? recf[1] : (b >> 1) == 2 ? recf[2] : recf[3];
-            // The sixteen operands end up in SCALAR register pairs (v_readfirstlane of the wave-uniform results: gfx950 has no scalar
-            // float unit), once per block: held in vector registers the compiler re-derived all of them from the records in every
-            // batch instead.
-            v2f Rx[4], Ry[4], Rz[4], Rs[4];   // 2 (r - c), and seed - |r - c|^2
-            auto uniform = [](v2f v) {
-                return v2f{__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.x))), __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v.y)))};
-            };
+            // The sixteen operands (and the centre) come from the receptor's table of them (BmModel::rec_ops, formed on the host) by
+            // SCALAR loads, straight into the scalar register pairs the batch's packed instructions take: no vector instruction.
+            // (Until round 5 a block's set-up formed them itself: 30 v_readlane of the tile's records, 45 packed operations, 32
+            // v_readfirstlane -- 110 of a set-up's ~500 vector instructions; before that, in vector registers, the compiler
+            // re-derived all sixteen in every batch.)
+            typedef const __attribute__((address_space(4))) float const_f32;
+            const_f32 *ops = (const_f32 *)(uintptr_t)(T->m.rec_ops + ((size_t)RT * 8 + (size_t)b) * kBmOpsFloats);
+            v2f Rx[4], Ry[4], Rz[4], Rs[4];   // seed - |r - c|^2, and 2 (r - c)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int at = (b & 1) * 32 + q * 8;   // record q of the subtile: x0 x1 y0 y1 z0 z1 . .
-                const v2f x = v2f{lane_f32(rec_here, at), lane_f32(rec_here, at + 1)} - v2f{cbx, cbx};
-                const v2f y = v2f{lane_f32(rec_here, at + 2), lane_f32(rec_here, at + 3)} - v2f{cby, cby};
-                const v2f z = v2f{lane_f32(rec_here, at + 4), lane_f32(rec_here, at + 5)} - v2f{cbz, cbz};
-                Rs[q] = uniform(__builtin_elementwise_fma(-x, x, __builtin_elementwise_fma(-y, y, __builtin_elementwise_fma(-z, z, v2f{seed, seed}))));
-                Rx[q] = uniform(x * v2f{2.f, 2.f});
-                Ry[q] = uniform(y * v2f{2.f, 2.f});
-                Rz[q] = uniform(z * v2f{2.f, 2.f});
+                Rs[q] = v2f{ops[2 * q], ops[2 * q + 1]};
+                Rz[q] = v2f{ops[8 + 2 * q], ops[9 + 2 * q]};
+                Ry[q] = v2f{ops[16 + 2 * q], ops[17 + 2 * q]};
+                Rx[q] = v2f{ops[24 + 2 * q], ops[25 + 2 * q]};
             }
+            const float cbx = ops[32], cby = ops[33], cbz = ops[34];
             if (DEBUG) dbg_t_block += now() - dbg_tblk;   // block set-up
 
             // ---- one batch: lane = entry.  WAVE = this wave's number in the workgroup, a constant of the code.
@@ -994,19 +1032,25 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 v2f LX[4], LY[4], LZ[4], L2[4];   // atoms (2p, 2p + 1): l - c and |l - c|^2
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
-                    const v2f X = reinterpret_cast<const v2f *>(WS.lig_local[0])[p], Y = reinterpret_cast<const v2f *>(WS.lig_local[1])[p];
-                    const v2f Z = reinterpret_cast<const v2f *>(WS.lig_local[2])[p];
-                    LD_BM_POSE_ASM(LX[p], LY[p], LZ[p], L2[p], A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, X, Y, Z);
+                    LD_BM_POSE_ASM(LX[p], LY[p], LZ[p], L2[p], A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, LocX[p], LocY[p], LocZ[p]);
                 }
                 // The batch's 64 pairs: dfire_bm_batch.inc (generated, tools/gen_bm_batch_asm.py).  Fixed-point sum: table
                 // values are integers (2^-k units, exact adds in any order); a flagged cell's slot holds the row's marker.
                 unsigned long long acc0 = 0ull, acc1 = 0ull;   // over the pairs with receptor atoms 0 2 4 6 / 1 3 5 7 of the subtile
+#ifndef LD_BM_DIAG_NO_PAIRS
                 LD_BM_BATCH_ASM(acc0, acc1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX, kCube);
+#else
+                asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(L2[0]), "v"(L2[1]), "v"(L2[2]), "v"(L2[3]), "v"(LX[0]), "v"(LY[0]), "v"(LZ[0]), "s"(Rs[0]), "s"(Rx[3]));
+#endif
                 // each sum = marker bits + the true sum, |true sum| < 2^50 (32 pairs; the scale is chosen for that)
-                const long long sum0 = (long long)acc0, sum1 = (long long)acc1;
-                const long long mark0 = (sum0 + (1ll << (kBmMarkerShift - 1))) >> kBmMarkerShift, mark1 = (sum1 + (1ll << (kBmMarkerShift - 1))) >> kBmMarkerShift;
-                const long long part = (sum0 - (mark0 << kBmMarkerShift)) + (sum1 - (mark1 << kBmMarkerShift));
-                const long long mark = mark0 | mark1;   // (one of them 0: the other's value)
+                // (the marker bits live in the sums' upper words -- bit 51 is bit 19 there, and rounding by 2^50 never carries out of
+                // the lower word: 32-bit arithmetic does what 64-bit shifts and subtractions did in twice the instructions)
+                static_assert(kBmMarkerShift > 33, "the markers sit in the upper word");
+                constexpr int kHiShift = kBmMarkerShift - 32;
+                const int mark0 = ((int)(uint32_t)(acc0 >> 32) + (1 << (kHiShift - 1))) >> kHiShift, mark1 = ((int)(uint32_t)(acc1 >> 32) + (1 << (kHiShift - 1))) >> kHiShift;
+                const unsigned long long both = acc0 + acc1;
+                const long long part = (long long)(((unsigned long long)((uint32_t)(both >> 32) - ((uint32_t)(mark0 + mark1) << kHiShift)) << 32) | (uint32_t)both);
+                const int mark = mark0 | mark1;   // (one of them 0: the other's value)
                 const bool any_flagged = valid && mark != 0;
                 const bool one = any_flagged && (mark0 == 0 || mark1 == 0) && mark >= 64 && mark < 128, several = any_flagged && !one;
                 const unsigned long long m1 = __ballot(one), m2 = __ballot(several);
@@ -1047,6 +1091,9 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 asm volatile("" :: "v"(next.a0.x), "v"(next.a0.y), "v"(next.a0.z), "v"(next.a0.w), "v"(next.a1.x), "v"(next.a1.y), "v"(next.a1.z), "v"(next.a1.w),
                              "v"(next.a2.x), "v"(next.a2.y), "v"(next.a2.z), "v"(next.a2.w), "v"(next.prev));
                 const BatchLoads cur = next;
+#ifdef LD_BM_DIAG_WAIT   // (diagnostic builds: the drain timer holds the time a wave waits at the head of its batches for their loads)
+                if (DEBUG) dbg_t_drain += now() - dbg_tb;
+#endif
                 flush_pending();   // (in front of the next batch's loads)
                 // the rows' markers, over what the copy left in their slots (they name the PAIR: not part of the table); in a block
                 // with an atom that has an interface-flag slot also in place of bins 0 and 1: those pairs go to the exact path, which
@@ -1061,13 +1108,18 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 // (in the code all waves share, and unconditional -- the block's last batch asks for its first items again -- so that the
                 // loads land in the registers the next trip reads them from: behind a branch the compiler moved them there
                 // right away, i.e. waited for them)
-                next = issue_loads(done + 64 < n_items ? done + 64 : 0u);
+                next = issue_loads(look_item, look_row);
+                const uint32_t in_row = read_row(look2_item);                   // batch k + 2's row
+                const uint32_t in_item = read_item(first_of(done + 192u));      // batch k + 3's item
                 switch (wave) {
                     case 0: run_batch(std::integral_constant<int, 0>{}, cur, done); break;
                     case 1: run_batch(std::integral_constant<int, 1>{}, cur, done); break;
                     case 2: run_batch(std::integral_constant<int, 2>{}, cur, done); break;
                     default: run_batch(std::integral_constant<int, 3>{}, cur, done); break;
                 }
+                look_item = look2_item;
+                look_row = in_row;
+                look2_item = in_item;
                 if (DEBUG) dbg_t_batch += now() - dbg_tb;
 #ifdef LD_BM_DIAG_FIRST   // (diagnostic builds: the drain timer holds the time of every block's FIRST batch -- the wait for the rows and the first loads)
                 if (DEBUG && done == 0) dbg_t_drain += now() - dbg_tb;

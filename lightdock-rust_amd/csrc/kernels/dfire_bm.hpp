@@ -70,6 +70,7 @@ __host__ __device__ inline uint32_t bm_code_of_bin(uint32_t bin) { return 8 * bi
 constexpr int kBmMarkerShift = 51;           // a lane keeps two sums of 32 pairs each: below 2^50 under it, 32 markers of at most 127 above it: 63 bits
 constexpr int kBmJobRows = 8;                // a job = (tile pair, part of its entries, ligand subtile a): the blocks (a, 0..7); one partial sum per (entry, a)
 constexpr int kBmPartEntries = 1024;         // entries of a tile pair in one job
+constexpr int kBmOpsFloats = 36;             // BmModel::rec_ops: Rs[4][2], Rz[4][2], Ry[4][2], Rx[4][2], cx, cy, cz, 0
 constexpr int kBmCubeRows = 64;              // table rows of a block: 8 ligand x 8 receptor atoms
 constexpr int kBmCubeBytes = kBmCubeRows * kBmRowBytes;
 constexpr int kBmTypes = 170;                // 169 DFIRE types + one all-zero type for padding atoms
@@ -118,6 +119,9 @@ struct BmModel {
     const TiledBox *rec_sub = nullptr;          // [n_tiles*8]
     const TiledBox *rec_tile = nullptr;         // [n_tiles]
     const uint32_t *rec_rowoff = nullptr;       // [n_tiles*64]: byte offset of the atom's type column in a table row block
+    const float *rec_ops = nullptr;             // [n_tiles*8][kBmOpsFloats]: a receptor subtile as the pair kernel's batches take it -- the centre c of its box
+                                                // and per pair record the packed operands seed - |r - c|^2, 2 (r - c)_z, _y, _x (f32, formed on the host by
+                                                // the operations bm_recheck repeats on the device): a block's set-up is three scalar loads
     const double *rec_x = nullptr, *rec_y = nullptr, *rec_z = nullptr;  // f64, tile order (exact path)
     const uint32_t *rec_tindex = nullptr;       // tile order: tiled_rec_term (exact path reads the patch table)
     const int32_t *rec_slot = nullptr;

@@ -871,6 +871,32 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
         M.rec_pairs = pairs;
         M.rec_sub = sub;
         M.rec_tile = tile;
+        {   // every receptor subtile's packed operands (BmModel::rec_ops): E = (seed - |r - c|^2) - |l - c|^2 + 2 (r - c) . (l - c), dfire_bm.hip.
+            // f32, operation by operation what bm_recheck computes on the device (IEEE: the same bits).
+            std::vector<PackedRecPair> hp(pad / 2);
+            std::vector<TiledBox> hb(pad / 8);
+            hip_check(hipMemcpy(hp.data(), pairs, hp.size() * sizeof(PackedRecPair), hipMemcpyDeviceToHost), "D2H receptor records");
+            hip_check(hipMemcpy(hb.data(), sub, hb.size() * sizeof(TiledBox), hipMemcpyDeviceToHost), "D2H receptor boxes");
+            const float seed = (float)kBmCellZero + 0.5f;
+            std::vector<float> ops((pad / 8) * (size_t)kBmOpsFloats, 0.f);
+            for (size_t sbt = 0; sbt < pad / 8; sbt++) {
+                const TiledBox &box = hb[sbt];
+                const float cbx = 0.5f * (box.lox + box.hix), cby = 0.5f * (box.loy + box.hiy), cbz = 0.5f * (box.loz + box.hiz);
+                float *o = &ops[sbt * kBmOpsFloats];
+                for (int q = 0; q < 4; q++) {
+                    const PackedRecPair &r = hp[sbt * 4 + q];
+                    const float xs[2] = {r.x0 - cbx, r.x1 - cbx}, ys[2] = {r.y0 - cby, r.y1 - cby}, zs[2] = {r.z0 - cbz, r.z1 - cbz};
+                    for (int h = 0; h < 2; h++) {
+                        o[2 * q + h] = std::fmaf(-xs[h], xs[h], std::fmaf(-ys[h], ys[h], std::fmaf(-zs[h], zs[h], seed)));
+                        o[8 + 2 * q + h] = zs[h] * 2.f;
+                        o[16 + 2 * q + h] = ys[h] * 2.f;
+                        o[24 + 2 * q + h] = xs[h] * 2.f;
+                    }
+                }
+                o[32] = cbx; o[33] = cby; o[34] = cbz;
+            }
+            M.rec_ops = arena_.upload(ops);
+        }
     }
     const uint32_t kPad = std::numeric_limits<uint32_t>::max();
     {   // per atom: where its type's rows / column sit in the row table; padding atoms take the all-zero type

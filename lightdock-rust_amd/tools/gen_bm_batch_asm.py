@@ -83,7 +83,8 @@ def pose_block():
     lines.append("v_pk_fma_f32 %[l2], %[lx], %[lx], %[l2]")
     outs = ['[%s] "=&v"(%s)' % (name, arr) for name, arr in (("lx", "LX"), ("ly", "LY"), ("lz", "LZ"), ("l2", "L2"))]
     ins = ['[a%d%s] "v"(A%d%s)' % (r, h, r, h) for r in range(3) for h in ("xy", "zw")]
-    ins += ['[%s] "v"(%s)' % (c, arr) for c, arr in (("x", "X"), ("y", "Y"), ("z", "Z"))]
+    # (X, Y, Z: wave-uniform, SCALAR register pairs -- read back from LDS per batch they were an LDS round trip at the head of every batch)
+    ins += ['[%s] "s"(%s)' % (c, arr) for c, arr in (("x", "X"), ("y", "Y"), ("z", "Z"))]
     return lines, outs, ins
 
 
