@@ -484,6 +484,9 @@ __global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_census(const BmLa
             const uint32_t it = (lane & 1) ? word >> 16 : word & 0xffffu;
             const uint32_t blocks = (uint32_t)__popc(((lane < 4 ? present_lo : present_hi) >> (8 * (lane & 3))) & 0xffu);
             T->job_cost[(size_t)jd * kBmJobRows + lane] = it ? it + 96u * blocks + 224u : 0u;
+            // the job's record, whole: what dfire_bm_pairs needs to start on it in ONE load behind its place in the order
+            // (tile pair, first entry, one past its last entry, ligand subtile)
+            reinterpret_cast<uint4 *>(T->job_rec)[(size_t)jd * kBmJobRows + lane] = uint4{(uint32_t)tp, lo, hi, (uint32_t)lane};
         }
     }
 }
@@ -637,8 +640,14 @@ __device__ __forceinline__ void bm_exact_pairs(BmArgs *T, unsigned long long *qu
             lterm[u] = (uint32_t)lw; lslot[u] = (int32_t)(lw >> 32);
             rterm[u] = (uint32_t)rw; rslot[u] = (int32_t)(rw >> 32);
         }
+        // the reference's arithmetic for the four pairs first, then their four table reads TOGETHER, then the sums: with the read
+        // inside each pair's branch a trip paid four dependent round trips to the L2 one after the other
+        bool inside[U];
+        uint32_t slot_at[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
+            inside[u] = false;
+            slot_at[u] = 0u;
             if (!act[u]) continue;
             if (T->exact_pairs) atomicAdd(T->exact_pairs + row[u], 1u);
             // the ligand atom as the reference poses it (src/dfire.rs:282-302: pose_ligand_atom's operations), then exact_pair's
@@ -655,8 +664,17 @@ __device__ __forceinline__ void bm_exact_pairs(BmArgs *T, unsigned long long *qu
                 if (rslot[u] >= 0) atomicOr(&flags[rslot[u] >> 5], 1u << (rslot[u] & 31));
                 if (lslot[u] >= 0) atomicOr(&flags[T->m.rec_flag_words + (lslot[u] >> 5)], 1u << (lslot[u] & 31));
             }
+            inside[u] = true;
+            slot_at[u] = (lterm[u] + rterm[u] + tiled_bin_term(bin)) / 8u;
+        }
+        double value[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) value[u] = ex0.table[slot_at[u]];   // (slot 0 for the pairs that read nothing: a valid address)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!inside[u]) continue;
             // a counting launch sums ones: the pair counts if it is within the cutoff
-            const long long fix = T->count_mode ? 1ll : __double2ll_rn(ex0.table[(lterm[u] + rterm[u] + tiled_bin_term(bin)) / 8u] * T->m.fix_scale);
+            const long long fix = T->count_mode ? 1ll : __double2ll_rn(value[u] * T->m.fix_scale);
             if (fix != 0) atomicAdd(reinterpret_cast<unsigned long long *>(T->exact_fix + row[u]), (unsigned long long)fix);
         }
     }
@@ -760,7 +778,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
     }
     BmWaveShared &WS = S.w[wave];
     __syncthreads();
-    const uint32_t n_jobs = T->job_count[3], part_entries = T->job_count[2];
+    const uint32_t n_jobs = T->job_count[3];
     const bool wide_rows = T->n_poses > 65536;   // (a pass of more than 2^16 rows: a GSO over hundreds of swarms)
     unsigned long long *queue = T->queue + ((size_t)blockIdx.x * kBmWaves + wave) * kBmQueueCap;   // the wave's flagged pairs
     unsigned long long *queue_blocks = queue + kBmQueuePairs;                                        // (entry, block) items with several
@@ -777,12 +795,12 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         job = (uint32_t)__builtin_amdgcn_readfirstlane((int)job);
         if (job >= n_jobs) break;
         job = T->job_order[job];   // longest first (dfire_bm_order)
-        const uint32_t jd = job / (uint32_t)kBmJobRows;
-        const int a = (int)(job % (uint32_t)kBmJobRows);   // ligand subtile a of the tile = partial-sum row of the entry
-        const size_t tp = T->jobs[2 * jd];
-        const uint32_t lo = T->jobs[2 * jd + 1];
-        const uint32_t n = T->tp_count[tp];
-        const uint32_t part_size = bm_part_size(n, part_entries), hi = n < lo + part_size ? n : lo + part_size;
+        // (the job's record as dfire_bm_census wrote it: one load; its pieces one by one -- the (tile pair, part) pair, then the tile
+        // pair's entry count -- were two more dependent round trips per job)
+        const uint4 rec = reinterpret_cast<const uint4 *>(T->job_rec)[job];
+        const size_t tp = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)rec.x);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.y), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.z);
+        const int a = __builtin_amdgcn_readfirstlane((int)rec.w);   // ligand subtile a of the tile = partial-sum row of the entry
         const int n_chunks = (int)((hi - lo + 63) / 64);
         const int lt = (int)(tp / (unsigned)n_rt), RT = (int)(tp % (unsigned)n_rt);
         const int ls = lt * 8 + a;

@@ -173,6 +173,7 @@ struct BmLaunch {
                                            // entries per part, jobs listed in job_order
     uint32_t *job_next = nullptr;
     uint32_t *job_cost = nullptr;          // [(tile pair, part)][kBmJobRows]: estimated length of the job (0: no block of that row in any entry)
+    uint32_t *job_rec = nullptr;           // [(tile pair, part)][kBmJobRows][4]: tile pair, first entry, one past the last, row -- written by dfire_bm_census
     uint32_t *job_order = nullptr;         // the jobs ((tile pair, part) index * kBmJobRows + row) that have work, longest first
     unsigned long long *queue = nullptr;   // [waves of dfire_bm_pairs][kBmQueueCap]: pairs waiting for the exact path
     int pairs_groups = 0;                  // CUs dfire_bm_pairs / dfire_bm_cull may fill (0: the 256 of an MI355X)

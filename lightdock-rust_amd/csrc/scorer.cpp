@@ -1066,6 +1066,7 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         t.jobs = static_cast<uint32_t *>(ws_bm_jobs_.ptr) + w * parts * 2;
         t.job_cost = static_cast<uint32_t *>(ws_bm_job_cost_.ptr) + w * parts * kBmJobRows;
         t.job_order = static_cast<uint32_t *>(ws_bm_job_order_.ptr) + w * parts * kBmJobRows;
+        t.job_rec = static_cast<uint32_t *>(ws_bm_job_order_.ptr) + bm_sets(n) * parts * kBmJobRows + w * parts * kBmJobRows * 4;
         t.queue = static_cast<unsigned long long *>(ws_bm_queue_.ptr) + w * waves * kBmQueueCap;
         t.ent_row = static_cast<uint32_t *>(ws_bm_ent_row_.ptr) + w * tile_pairs * cap;
         t.ent_mask = static_cast<unsigned long long *>(ws_bm_ent_mask_.ptr) + w * tile_pairs * cap;
@@ -1199,7 +1200,7 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         ws_bm_tp_count_.reserve(sets * (tile_pairs + kBmCounters + kBmCullQueueWords) * sizeof(uint32_t));   // + the launch's counters
         ws_bm_jobs_.reserve(sets * parts * 2 * sizeof(uint32_t));
         ws_bm_job_cost_.reserve(sets * parts * kBmJobRows * sizeof(uint32_t));
-        ws_bm_job_order_.reserve(sets * parts * kBmJobRows * sizeof(uint32_t));
+        ws_bm_job_order_.reserve(sets * parts * kBmJobRows * (1 + 4) * sizeof(uint32_t) + 16);   // the order, then the jobs' 16-byte records
         ws_bm_queue_.reserve(sets * waves * kBmQueueCap * sizeof(unsigned long long));
         // (+ one part: a job of dfire_bm_pairs loads its part's 1024 entries without looking at the part's end; what lies beyond is never used)
         ws_bm_ent_row_.reserve((sets * tile_pairs * cap + kBmPartEntries) * sizeof(uint32_t));
