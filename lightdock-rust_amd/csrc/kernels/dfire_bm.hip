@@ -1055,7 +1055,42 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 // The batch's 64 pairs: dfire_bm_batch.inc (generated, tools/gen_bm_batch_asm.py).  Fixed-point sum: table
                 // values are integers (2^-k units, exact adds in any order); a flagged cell's slot holds the row's marker.
                 unsigned long long acc0 = 0ull, acc1 = 0ull;   // over the pairs with receptor atoms 0 2 4 6 / 1 3 5 7 of the subtile
-#ifndef LD_BM_DIAG_NO_PAIRS
+#if defined(LD_BM_DIAG_ANM_COST)
+                // Timing experiment (wrong sums): what a block-major batch would cost for molecules that FLEX per pose
+                // (src/dfire.rs:288-320: 10 + 10 normal modes) -- per lane the ligand subtile's deformation (8 atoms x 3 coordinates x 10
+                // modes = 240 multiply-adds = 120 packed), the receptor subtile's (120 packed) and its sixteen operands per lane (36
+                // packed: the batch then takes them from vector registers), and 80 more bytes per item: the pose's 20 mode amplitudes.
+                {
+                    const float4 *amp = reinterpret_cast<const float4 *>(T->poses + (size_t)(cur.row % (uint32_t)T->n_poses) * T->stride + 7);
+                    float4 q0 = amp[0], q1 = amp[1], q2 = amp[2], q3 = amp[3], q4 = amp[4];
+                    v2f t0{q0.x, q0.y}, t1{q1.x, q1.y}, t2{q2.x, q2.y}, t3{q3.x + q4.x, q3.y};
+#ifndef LD_BM_DIAG_ANM_LDS
+                    asm volatile(".rept 69\n\tv_pk_fma_f32 %0, %4, %5, %0\n\tv_pk_fma_f32 %1, %4, %5, %1\n\tv_pk_fma_f32 %2, %4, %5, %2\n\tv_pk_fma_f32 %3, %4, %5, %3\n\t.endr"
+                                 : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(LX[0]), "v"(LY[0]));
+#else
+                    // ... and the 480 mode components of the two subtiles are wave-uniform: delivered from LDS, 120 broadcast reads of 16
+                    // bytes (one per four multiply-adds' worth of operands), four in flight
+                    {
+                        const uint32_t lds_at = (uint32_t)(uintptr_t)&WS.rows[0];   // (any 1 KB of the wave's LDS: the values do not matter here)
+                        asm volatile(".rept 30\n\t"
+                                     "ds_read_b128 v[220:223], %6\n\tds_read_b128 v[224:227], %6 offset:16\n\tds_read_b128 v[228:231], %6 offset:32\n\tds_read_b128 v[232:235], %6 offset:48\n\t"
+                                     "s_waitcnt lgkmcnt(0)\n\t"
+                                     "v_pk_fma_f32 %0, %4, v[220:221], %0\n\tv_pk_fma_f32 %1, %4, v[222:223], %1\n\tv_pk_fma_f32 %2, %5, v[224:225], %2\n\tv_pk_fma_f32 %3, %5, v[226:227], %3\n\t"
+                                     "v_pk_fma_f32 %0, %4, v[228:229], %0\n\tv_pk_fma_f32 %1, %4, v[230:231], %1\n\tv_pk_fma_f32 %2, %5, v[232:233], %2\n\tv_pk_fma_f32 %3, %5, v[234:235], %3\n\t"
+                                     ".endr\n\t"
+                                     ".rept 9\n\tv_pk_fma_f32 %0, %4, %5, %0\n\tv_pk_fma_f32 %1, %4, %5, %1\n\tv_pk_fma_f32 %2, %4, %5, %2\n\tv_pk_fma_f32 %3, %4, %5, %3\n\t.endr"
+                                     : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(LX[0]), "v"(LY[0]), "v"(lds_at)
+                                     : "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "memory");
+                    }
+#endif
+                    v2f vRs[4], vRz[4], vRy[4], vRx[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        vRs[q] = Rs[q] + t0 * v2f{0.f, 0.f}; vRz[q] = Rz[q] + t1 * v2f{0.f, 0.f}; vRy[q] = Ry[q] + t2 * v2f{0.f, 0.f}; vRx[q] = Rx[q] + t3 * v2f{0.f, 0.f};
+                    }
+                    LD_BM_BATCH_ASM_V(acc0, acc1, vRs, vRz, vRy, vRx, L2, LZ, LY, LX, kCube);
+                }
+#elif !defined(LD_BM_DIAG_NO_PAIRS)
                 LD_BM_BATCH_ASM(acc0, acc1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX, kCube);
 #else
                 asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(L2[0]), "v"(L2[1]), "v"(L2[2]), "v"(L2[3]), "v"(LX[0]), "v"(LY[0]), "v"(LZ[0]), "s"(Rs[0]), "s"(Rx[3]));

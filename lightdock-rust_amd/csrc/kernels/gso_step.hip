@@ -248,7 +248,7 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
 // the groups they were computed once per 8 glowworms of a wave instead of once per 64: a step of 1024 quiet swarms took twice
 // as long), the hand-over goes through LDS.  Measured on one box, 1024 swarms x 200 of 1ppe, step time quiet / 1 % alive / all
 // alive: a thread per glowworm 0.062 / 0.310 / 5.35 ms, this kernel 0.087 / 0.278 / 5.45; 64 swarms of 1k4c: 1.447 against
-// 1.396 ms.  So: this one up to 16 384 glowworms, the other beyond.
+// 1.396 ms.  So: this one up to 16 384 glowworms, the other beyond (round 4; round 5 moved the line to 102 400: launch_gso_step).
 __global__ __launch_bounds__(1024) void gso_movement_phased(const GsoLaunch G) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int N = G.n_glowworms;
@@ -344,7 +344,16 @@ __global__ __launch_bounds__(1024) void gso_movement_phased(const GsoLaunch G) {
 size_t gso_kernel_lds_bytes(const GsoLaunch &g, bool phased) { return (size_t)(phased ? 6 : 4) * g.n_glowworms * sizeof(double); }
 
 bool gso_step_is_phased(const GsoLaunch &g) {
-    const bool small = (size_t)g.n_swarms * g.n_glowworms <= 16384;   // (up to 64 swarms of 200 on an MI355X: see gso_movement_phased)
+    // Up to 102 400 glowworms (512 swarms of 200) the phased kernel: a live swarm's step is a LATENCY (a thread of the other kernel walks
+    // its swarm's N glowworms twice, ~100 us at N = 200 whatever the launch's size), and that latency is what a GPU's share of
+    // BASELINE config 5 pays per step -- 128 swarms: 0.823 -> 0.766 ms per step, 256: 1.395 -> 1.356, 512: 2.704 -> 2.698 (round 5,
+    // one box; round 4 drew the line at 16 384).  Beyond, eight times the threads cost more than the latency they save.
+    // (A hybrid for the launches beyond -- workgroups sized for the phased path that take it only for swarms in which something
+    // moved in the previous step, and only while fewer than an eighth of all glowworms did -- was built and measured in round 5,
+    // 1024 swarms: 1 % alive 0.301 -> 0.282 ms per step, but the step in which nothing moves 0.062 -> 0.100 and everything alive
+    // 5.28 -> 5.56: sixteen waves per workgroup where four do the work, and a reduction over the swarm's moved flags in
+    // front of every workgroup.  Not kept.)
+    const bool small = (size_t)g.n_swarms * g.n_glowworms <= 102400;
     const char *mode = std::getenv("LIGHTDOCK_GSO_K2");   // diagnostics / tests: "single" / "phased" whatever the size
     const std::string m = mode ? mode : "";
     bool phased = m == "phased" || (m != "single" && small);

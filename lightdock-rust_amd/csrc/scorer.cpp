@@ -789,8 +789,11 @@ double dfire_bm_fix_scale(double vmax, size_t reach_count, int *extra_bits_out) 
 
 void Scorer::build_bm(const ld_scorer_desc &desc) {
     // rigid molecules only: with ANM the ligand's local coordinates (and the receptor image) change per pose
-    if (use_anm_ && (desc.receptor.num_anm > 0 || desc.ligand.num_anm > 0)) return;
-    if (rec_anm_per_pose_) return;
+    // (LIGHTDOCK_BM_DIAG_IGNORE_ANM=1: timing experiments only -- the block-major kernels on an ANM complex as if it were rigid, wrong sums)
+    const char *ignore_anm = std::getenv("LIGHTDOCK_BM_DIAG_IGNORE_ANM");
+    const bool diag_rigid = ignore_anm && std::atoi(ignore_anm) == 1;
+    if (!diag_rigid && use_anm_ && (desc.receptor.num_anm > 0 || desc.ligand.num_anm > 0)) return;
+    if (!diag_rigid && rec_anm_per_pose_) return;
     const TiledSoA &rec = tiled_rec_soa_, &lig = tiled_lig_soa_;
     if (rec.n_tiles > 1024 || lig.n_tiles > 1024) return;  // an item of the exact path names its atoms in 16 bits each
     if (bm_cull_lds_bytes(rec.n_tiles) + 1024 > kBmLdsPerCu) return;  // the culling kernel keeps every receptor box in LDS: ~430 tiles at most

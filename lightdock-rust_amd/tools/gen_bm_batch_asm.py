@@ -126,23 +126,29 @@ def main():
         if 1 <= h <= 8:
             lines += stage_b(h - 1)
     body = " \\\n".join('    "%s\\n\\t"' % l for l in lines)
-    ops_in = []
-    for name in ("rs", "rz", "ry", "rx"):
-        # the block's receptor operands are wave-uniform: SCALAR register pairs (a packed instruction takes one as its first source).
-        # As vector registers the compiler kept the raw records in scalar registers and RECOMPUTED all sixteen operands in every
-        # batch (36 packed instructions + the box centre: a ninth of a batch's vector instructions) rather than hold 32 registers.
-        ops_in += ['[%s%d] "s"(%s[%d])' % (name, g, {"rs": "Rs", "rz": "Rz", "ry": "Ry", "rx": "Rx"}[name], g) for g in range(4)]
-    for name, arr in (("l2", "L2"), ("lz", "LZ"), ("ly", "LY"), ("lx", "LX")):
-        ops_in += ['[%s%d] "v"(%s[%d])' % (name, p, arr, p) for p in range(4)]
+    def operands(r_constraint):
+        ops = []
+        for name in ("rs", "rz", "ry", "rx"):
+            # the block's receptor operands are wave-uniform: SCALAR register pairs (a packed instruction takes one as its first source).
+            # As vector registers the compiler kept the raw records in scalar registers and RECOMPUTED all sixteen operands in every
+            # batch (36 packed instructions + the box centre: a ninth of a batch's vector instructions) rather than hold 32 registers.
+            # (The form with vector registers, LD_BM_BATCH_ASM_V, is what a block-major kernel for molecules that flex per pose would
+            # need -- receptor atoms differ per lane; it exists for the timing experiment LD_BM_DIAG_ANM_COST only.)
+            ops += ['[%s%d] "%s"(%s[%d])' % (name, g, r_constraint, {"rs": "Rs", "rz": "Rz", "ry": "Ry", "rx": "Rx"}[name], g) for g in range(4)]
+        for name, arr in (("l2", "L2"), ("lz", "LZ"), ("ly", "LY"), ("lx", "LX")):
+            ops += ['[%s%d] "v"(%s[%d])' % (name, p, arr, p) for p in range(4)]
+        return ops
+    ops_in = operands("s")
     clobbers = ", ".join('"v%d"' % r for r in range(220, 256))
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.path.join(here, "..", "csrc", "kernels", "dfire_bm_batch.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by lightdock-rust_amd/tools/gen_bm_batch_asm.py -- do not edit; the generator's docstring explains the schedule.\n")
         f.write("// %d instructions: %d vector, %d LDS, %d waits.\n" % (len(lines), sum(l.startswith("v_") for l in lines), sum(l.startswith("ds_") for l in lines), sum(l.startswith("s_waitcnt") for l in lines)))
-        f.write("#define LD_BM_BATCH_ASM(SUM0, SUM1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX, CUBE) \\\n  asm volatile( \\\n" + body + " \\\n")
-        f.write('    : [acc] "+v"(SUM0), [acc1] "+v"(SUM1) \\\n    : ' + ", \\\n      ".join(ops_in) + ', \\\n      [cube] "n"(CUBE) \\\n')
-        f.write("    : " + clobbers + ', "memory")\n')
+        for macro, ops in (("LD_BM_BATCH_ASM", ops_in), ("LD_BM_BATCH_ASM_V", operands("v"))):
+            f.write("#define %s(SUM0, SUM1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX, CUBE) \\\n  asm volatile( \\\n" % macro + body + " \\\n")
+            f.write('    : [acc] "+v"(SUM0), [acc1] "+v"(SUM1) \\\n    : ' + ", \\\n      ".join(ops) + ', \\\n      [cube] "n"(CUBE) \\\n')
+            f.write("    : " + clobbers + ', "memory")\n\n')
         plines, pouts, pins = pose_block()
         f.write("\n// two of the lane's 8 ligand atoms posed: %d packed instructions\n" % len(plines))
         f.write("#define LD_BM_POSE_ASM(LX, LY, LZ, L2, A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, X, Y, Z) \\\n  asm( \\\n")

@@ -765,14 +765,13 @@ def test_gso_odd_sizes(pkg, scorers, orc, monkeypatch):
 
 @pytest.mark.parametrize("shape", K2_SHAPES)
 def test_gso_many_swarms_in_both_k2_shapes(pkg, scorers, orc, monkeypatch, shape):
-    """The same batch of swarms through either shape of K2: 96 swarms x 200 glowworms (19 200 glowworms: beyond the phased
-    kernel's own range, so `phased` is forced onto a launch the thread-per-glowworm kernel would take, and `single` onto
-    nothing new) and 6 x 64 (384: the phased kernel's range, `single` forced) -- sampled swarms equal the oracle, replicated
-    swarms stay bit-identical, the evaluation counts agree."""
+    """The same batch of swarms through either shape of K2: 96 swarms x 200 glowworms and 6 x 64 (both inside the phased
+    kernel's own range of 102 400 glowworms: `single` is what gets forced) and 520 x 200 (104 000: beyond it, `phased` forced)
+    -- sampled swarms equal the oracle, replicated swarms stay bit-identical."""
     _k2_env(monkeypatch, shape)
     hip, cpu = scorers("1ppe")
     base = case_positions("1ppe", orc)
-    for n_swarms, n, steps, sample in ((96, 200, 5, (0, 41, 95)), (6, 64, 8, (0, 1, 5))):
+    for n_swarms, n, steps, sample in ((96, 200, 5, (0, 41, 95)), (6, 64, 8, (0, 1, 5)), (520, 200, 3, (0, 519))):
         swarms = [base[:n]] + [pkg.synth.swarm(n, seed=100 + k) for k in range(1, n_swarms)]
         swarms[n_swarms - 1] = swarms[1]
         gso = pkg.GSO(hip, np.stack(swarms))
