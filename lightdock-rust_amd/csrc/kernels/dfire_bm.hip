@@ -140,6 +140,21 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
         }
         if (T->exact_fix) T->exact_fix[listed] = 0;
         if (T->exact_pairs) T->exact_pairs[listed] = 0;
+        if (T->amp != nullptr) {   // the pose's mode amplitudes as the pair kernel loads them (f32: their rounding is part of eps), and whether it is WILD
+            float *am = T->amp + listed * kBmAmpFloats;
+            float reach_rec = 0.f, reach_lig = 0.f;
+#pragma unroll
+            for (int k = 0; k < kBmMaxModes; k++) {
+                const float ar = k < T->m.anm_rec ? (float)row[7 + k] : 0.f, al = k < T->m.anm_lig ? (float)row[7 + T->m.anm_rec + k] : 0.f;
+                am[k] = ar;
+                am[kBmMaxModes + k] = al;
+                reach_rec = __builtin_fmaf(fabsf(ar), T->m.rec_mode_reach[k], reach_rec);
+                reach_lig = __builtin_fmaf(fabsf(al), T->m.lig_mode_reach[k], reach_lig);
+            }
+            // (NaN amplitudes: not below the bound either -> wild -> the exact path, where the reference's arithmetic decides)
+            am[20] = reach_rec <= kBmWildUnits && reach_lig <= kBmWildUnits ? 0.f : 1.f;
+            am[21] = am[22] = am[23] = 0.f;
+        }
     }
 }
 
@@ -149,7 +164,10 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
 // tile: ONE atomic per tile pair for all the poses of the wave (the lists of a small complex have few heads: one
 // returning atomic per pose and tile pair serialises on them), then the entries.
 // ---------------------------------------------------------------------------------------------
-template <bool COUNT>
+// ANM (DFIRE with normal modes, src/dfire.rs:288-320): the receptor's boxes differ per pose -- read from the per-pose images
+// dfire_packed_prepare wrote (BmLaunch::anm_sub / anm_tile) instead of the static ones in LDS -- and the ligand tile's atoms are
+// flexed after the affine map: + sum_k amplitude_k x mode_k of the atom (kappa x, f32; the amplitudes from the [row] table).
+template <bool COUNT, bool ANM>
 __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
     // LDS: the receptor's subtile and tile boxes (read by every item; a global load per surviving tile was most of an
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     uint32_t *s_hkey = s_base + n_rt;                                                       // [hit_cap]: pose of the wave << 16 | receptor tile
     unsigned short *s_hrank = reinterpret_cast<unsigned short *>(s_hkey + hit_cap);         // [hit_cap]: place among the wave's hits of that tile pair
     if (bm_rows(T) == 0) return;   // (a quiet GSO step)
-    {
+    if (!ANM) {
         static_assert(sizeof(TiledBox) == 32, "two 16-byte pieces");
         const uint4 *src_sub = reinterpret_cast<const uint4 *>(T->m.rec_sub), *src_tile = reinterpret_cast<const uint4 *>(T->m.rec_tile);
         for (int k = threadIdx.x; k < n_rt * 8; k += kBmCullWaves * 64) {
@@ -220,19 +238,45 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     const bool valid = loc.w != 0.f;
     const float4 sphere = reinterpret_cast<const float4 *>(T->m.lig_tile_sphere)[lt];
     // this lane's receptor tile box (the first 64 tiles; larger receptors read the rest per pose)
-    TiledBox my_tile = TiledBox{INFINITY, INFINITY, INFINITY, 0.f, -INFINITY, -INFINITY, -INFINITY, 0.f};
-    if (lane < n_rt) my_tile = s_tile[lane];
+    const TiledBox no_tile = TiledBox{INFINITY, INFINITY, INFINITY, 0.f, -INFINITY, -INFINITY, -INFINITY, 0.f};
+    TiledBox my_tile = no_tile;
+    if (!ANM && lane < n_rt) my_tile = s_tile[lane];
+    // ANM: this lane's atom's modes (kappa x, f32: [mode][x y z], 32 floats an atom), kept for the item's poses
+    float mode_x[kBmMaxModes], mode_y[kBmMaxModes], mode_z[kBmMaxModes];
+    if (ANM) {
+        const float4 *mp = reinterpret_cast<const float4 *>(T->m.lig_modes_atom) + (size_t)la * 8;
+        float4 q[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) q[k] = mp[k];
+        const float *f = reinterpret_cast<const float *>(q);
+#pragma unroll
+        for (int k = 0; k < kBmMaxModes; k++) {
+            mode_x[k] = f[3 * k];
+            mode_y[k] = f[3 * k + 1];
+            mode_z[k] = f[3 * k + 2];
+        }
+    }
 
     // the item's poses and their affine maps: lane g loads those of pose g, all in flight together
     long long my_pose = -1;   // (only its sign is used: the workspace of a pass goes by row)
     const uint32_t my_row = (uint32_t)(listed0 + lane);
     float4 my_a0 = float4{0.f, 0.f, 0.f, 0.f}, my_a1 = my_a0, my_a2 = my_a0;
     if (lane < group_poses && listed0 + lane < rows) my_pose = bm_pose_of(T, listed0 + lane);
+    float my_amp[kBmMaxModes];   // ANM: the pose's ligand amplitudes (lane g: pose g)
+    float my_wild = 0.f;
+#pragma unroll
+    for (int k = 0; k < kBmMaxModes; k++) my_amp[k] = 0.f;
     if (my_pose >= 0) {
         const float4 *ap = reinterpret_cast<const float4 *>(T->rt + (size_t)my_row * 12);
         my_a0 = ap[0];
         my_a1 = ap[1];
         my_a2 = ap[2];
+        if (ANM) {
+            const float *am = T->amp + (size_t)my_row * kBmAmpFloats + kBmMaxModes;
+#pragma unroll
+            for (int k = 0; k < kBmMaxModes; k++) my_amp[k] = am[k];
+            my_wild = am[kBmMaxModes];   // (the row's float 20)
+        }
     }
     auto pose_lane = [](float v, int g) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), g)); };
     auto affine_of = [&](int g) {
@@ -298,14 +342,44 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
             n_hits += held;
             held = 0;
         };
+        if (ANM && pose_lane(my_wild, g) != 0.f) {
+            // A WILD pose (amplitudes beyond what the f32 bounds cover, or not finite): no box is trusted -- every block of every
+            // tile pair is listed, the pair kernel sends them whole to the exact path, and the reference's arithmetic decides.
+            for (int base = 0; base < n_rt; base += 64) {
+                held = (uint32_t)(n_rt - base < 64 ? n_rt - base : 64);
+                held_lo = held_hi = 0xffffffffu;
+                held_key = (uint32_t)(g << 16 | (base + lane));
+                put_held();
+            }
+            if (COUNT && lane == 0) T->tile_tested[(listed0 + g) * (size_t)n_lt + lt] = (uint32_t)n_rt * 64u;
+            continue;
+        }
+        // ANM: this pose's receptor boxes (global memory, the pose's image) and how far its amplitudes can move a ligand atom
+        const TiledBox *tiles_g = nullptr;
+        const TiledBox *subs_g = nullptr;
+        float flex_reach = 0.f;
+        if (ANM) {
+            tiles_g = T->anm_tile + (size_t)pose_of[g] * n_rt;
+            subs_g = T->anm_sub + (size_t)pose_of[g] * n_rt * 8;
+            my_tile = lane < n_rt ? tiles_g[lane] : no_tile;
+#pragma unroll
+            for (int k = 0; k < kBmMaxModes; k++) flex_reach = __builtin_fmaf(fabsf(pose_lane(my_amp[k], g)), T->m.lig_mode_reach[k], flex_reach);
+            flex_reach *= 1.0001f;
+        }
+        auto tile_at = [&](int i) { return ANM ? tiles_g[i] : s_tile[i]; };
+        auto sub_at = [&](int i) {   // subtile i of the receptor as {lo, -hi} pairs
+            if (!ANM) return s_sub[i];
+            const TiledBox t = subs_g[i];
+            return BmCullBox{v2f{t.lox, -t.hix}, v2f{t.loy, -t.hiy}, v2f{t.loz, -t.hiz}, v2f{0.f, 0.f}};
+        };
         {   // A tile whose bounding sphere stays beyond the cutoff of every receptor tile's box has nothing to list (most tiles
             // of a large ligand, in most poses): one point posed and one test per receptor tile instead of 64 atoms posed,
             // their boxes and the box tests.
             const float sx = pose_lane(my_sx, g), sy = pose_lane(my_sy, g), sz = pose_lane(my_sz, g);
-            const float reach = 120.0f * 1.0001f + sphere.w + pad;   // (8 * 15 A, the sphere's radius, the affine map's error)
+            const float reach = 120.0f * 1.0001f + sphere.w + pad + flex_reach;   // (8 * 15 A, the sphere's radius, the affine map's error; ANM: what the modes can add)
             bool any_near = false;
             for (int base = 0; base < n_rt && !any_near; base += 64) {
-                const TiledBox tb = base == 0 ? my_tile : (base + lane < n_rt ? s_tile[base + lane] : my_tile);
+                const TiledBox tb = base == 0 ? my_tile : (base + lane < n_rt ? tile_at(base + lane) : my_tile);
                 const float gx = fmaxf(0.f, fmaxf(tb.lox - sx, sx - tb.hix));
                 const float gy = fmaxf(0.f, fmaxf(tb.loy - sy, sy - tb.hiy));
                 const float gz = fmaxf(0.f, fmaxf(tb.loz - sz, sz - tb.hiz));
@@ -319,6 +393,15 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         const Affine A = affine_of(g);
         float fx, fy, fz;
         bm_apply(A, loc.x, loc.y, loc.z, fx, fy, fz);
+        if (ANM) {   // + sum_k amplitude_k mode_k (src/dfire.rs:288-301: after the rotation and translation, in the receptor's frame)
+#pragma unroll
+            for (int k = 0; k < kBmMaxModes; k++) {
+                const float c = pose_lane(my_amp[k], g);
+                fx = __builtin_fmaf(c, mode_x[k], fx);
+                fy = __builtin_fmaf(c, mode_y[k], fy);
+                fz = __builtin_fmaf(c, mode_z[k], fz);
+            }
+        }
         const bool inside = fabsf(fx) <= ubound && fabsf(fy) <= ubound && fabsf(fz) <= ubound;
 
         // An atom outside the frame is more than the cutoff away from every receptor atom (the frame holds the receptor's
@@ -341,7 +424,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         for (int base = 0; base < n_rt; base += 64) {
             bool tile_near = false;
             if (base == 0) tile_near = lane < n_rt && box_gap2(whole, my_tile) <= kBmBoxCut;
-            else if (base + lane < n_rt) tile_near = box_gap2(whole, s_tile[base + lane]) <= kBmBoxCut;
+            else if (base + lane < n_rt) tile_near = box_gap2(whole, tile_at(base + lane)) <= kBmBoxCut;
             unsigned long long rtmask = __ballot(tile_near);
             if (rtmask) {
                 // one surviving tile at a time, the next one's subtile boxes loaded while this one's are tested (the last trip loads
@@ -349,12 +432,12 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                 // (two copies of the step, the boxes alternating between two sets of registers: no moves)
                 int RT_a = base + __ffsll(rtmask) - 1, RT_b = RT_a;
                 rtmask &= rtmask - 1;
-                BmCullBox nb_a = s_sub[RT_a * 8 + bj], nb_b;
+                BmCullBox nb_a = sub_at(RT_a * 8 + bj), nb_b;
                 auto step = [&](int RT, const BmCullBox &nb, int &RT_next, BmCullBox &nb_next) {
                     const bool more = rtmask != 0ull;
                     RT_next = more ? base + __ffsll(rtmask) - 1 : RT;
                     rtmask &= rtmask - 1;
-                    nb_next = s_sub[RT_next * 8 + bj];
+                    nb_next = sub_at(RT_next * 8 + bj);
 #ifdef LD_BM_DIAG_NO_TRACKED   // (diagnostic builds: timing only, wrong sums -- no block with a receptor subtile that holds a tracked atom, i.e. 1k4c's beads)
                     const unsigned long long smask = __ballot(bm_cull_gap2(sub_x, sub_y, sub_z, nb) <= kBmBoxCut && T->m.rec_sub_tracked[RT * 8 + bj] == 0);
 #else
@@ -415,7 +498,8 @@ __global__ __launch_bounds__(1024) void dfire_bm_plan(const BmLaunch launch_argu
 #define LD_BM_P_FACTOR 8
 #endif
     uint32_t P = (uint32_t)(((unsigned long long)s_total * LD_BM_P_FACTOR / waves + 63u) / 64u * 64u);
-    P = P < 64u ? 64u : P > (uint32_t)kBmPartEntries ? (uint32_t)kBmPartEntries : P;
+    const uint32_t part_cap = T->part_cap ? T->part_cap : (uint32_t)kBmPartEntries;   // (the ANM form of the pair kernel holds 512 entries a job)
+    P = P < 64u ? 64u : P > part_cap ? part_cap : P;
     for (uint32_t tp = tid; tp < n_tp; tp += 1024) {
         const uint32_t n = T->tp_count[tp];
         if (n == 0) continue;
@@ -544,19 +628,27 @@ __global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_order(const BmLau
 // The batch code exists once per wave of the workgroup (switch on the wave number): the LDS address of a cube row is a
 // constant of the instruction that reads it, so a pair's table address is `code - 8`, no base to add.
 // ---------------------------------------------------------------------------------------------
-struct BmWaveShared {
-    unsigned char row_bits[kBmPartEntries];        // per entry of the job: which of the 8 blocks (a, .) it holds
-    unsigned short items[kBmPartEntries];          // the entries that hold the current block (| 0x8000: its first block of the row)
-    unsigned short rows[kBmPartEntries];           // per entry of the job: its row of the pass (where its affine map is), bits 0..15
-    unsigned char rows_hi[kBmPartEntries / 4];     // ... and bits 16, 17: four entries to a byte (a pass holds up to 2^18 rows)
+// ANM: the form for molecules that flex per pose (src/dfire.rs:288-320): a job holds half the entries, and in their place the modes
+// of the job's ligand subtile and of the current block's receptor subtile (kappa x, f32, in the order a batch reads them).
+template <bool ANM>
+struct BmWaveSharedT {
+    static constexpr int kPart = ANM ? kBmAnmPartEntries : kBmPartEntries;
+    unsigned char row_bits[kPart];        // per entry of the job: which of the 8 blocks (a, .) it holds
+    unsigned short items[kPart];          // the entries that hold the current block
+    unsigned short rows[kPart];           // per entry of the job: its row of the pass (where its affine map is), bits 0..15
+    unsigned char rows_hi[kPart / 4];     // ... and bits 16, 17: four entries to a byte (a pass holds up to 2^18 rows)
+    alignas(16) float modes[ANM ? 2 * kBmModeFloats : 4];   // ANM: [ligand subtile][receptor subtile] x kBmModeFloats
 };
-struct BmShared {
+template <bool ANM>
+struct BmSharedT {
     unsigned char lut[kBmLutBytes];   // indexed from the far end: cell' = floor(kBmCellZero + 1/2 - 64 d2), everything further reads cell' 0
     unsigned char cube[kBmWaves][kBmCubeBytes];   // (in front of the per-wave lists: every cube row within the 16-bit offset field of a DS instruction)
-    BmWaveShared w[kBmWaves];
+    BmWaveSharedT<ANM> w[kBmWaves];
 };
-static_assert(sizeof(BmShared) * kBmGroupsPerCu <= 160 * 1024, "two workgroups per CU");
+typedef BmSharedT<false> BmShared;
+static_assert(sizeof(BmSharedT<false>) * kBmGroupsPerCu <= 160 * 1024 && sizeof(BmSharedT<true>) * kBmGroupsPerCu <= 160 * 1024, "two workgroups per CU");
 static_assert(offsetof(BmShared, cube) + sizeof(unsigned char[kBmWaves][kBmCubeBytes]) < 65536, "cube rows are addressed by instruction offsets");
+static_assert(offsetof(BmSharedT<true>, cube) == offsetof(BmShared, cube), "one batch code for both forms");
 
 // what a wave needs to evaluate queued items
 struct BmWaveCtx {
@@ -653,8 +745,27 @@ __device__ __forceinline__ void bm_exact_pairs(BmArgs *T, unsigned long long *qu
             // the ligand atom as the reference poses it (src/dfire.rs:282-302: pose_ligand_atom's operations), then exact_pair's
             const Quat q{pr[u][3], pr[u][4], pr[u][5], pr[u][6]};
             const Quat r = qmul(qmul(q, Quat{0.0, lc[u][0], lc[u][1], lc[u][2]}), qinverse(q));
-            const double px = r.x + pr[u][0], py = r.y + pr[u][1], pz = r.z + pr[u][2];
-            const double dx = 2.0 * rc[u][0] - 2.0 * px, dy = 2.0 * rc[u][1] - 2.0 * py, dz = 2.0 * rc[u][2] - 2.0 * pz;
+            double px = r.x + pr[u][0], py = r.y + pr[u][1], pz = r.z + pr[u][2];
+            double rx = rc[u][0], ry = rc[u][1], rz = rc[u][2];
+            if (T->amp != nullptr) {   // molecules that flex: src/dfire.rs:288-320, the operations of pose_ligand_atom and exact_pair (dfire_device.hpp)
+                const double *prow = T->poses + pose[u] * T->stride;
+                const size_t lpad = (size_t)T->m.lig.n_tiles * 64, rpad = T->m.rec_pad;
+                for (int k = 0; k < T->m.anm_lig; k++) {
+                    const double c = prow[7 + T->m.anm_rec + k];
+                    const double *m = T->m.lig.modes + (size_t)k * 3 * lpad;
+                    px += m[la[u]] * c;
+                    py += m[lpad + la[u]] * c;
+                    pz += m[2 * lpad + la[u]] * c;
+                }
+                for (int k = 0; k < T->m.anm_rec; k++) {
+                    const double c = prow[7 + k];
+                    const double *m = T->m.rec_modes + (size_t)k * 3 * rpad;
+                    rx += m[ra[u]] * c;
+                    ry += m[rpad + ra[u]] * c;
+                    rz += m[2 * rpad + ra[u]] * c;
+                }
+            }
+            const double dx = 2.0 * rx - 2.0 * px, dy = 2.0 * ry - 2.0 * py, dz = 2.0 * rz - 2.0 * pz;
             const double D = dx * dx + dy * dy + dz * dz;   // = 4 d2 bit for bit (src/dfire.rs:331-333)
             if (!(D <= kCutScaled)) continue;   // d2 <= 225 (src/dfire.rs:334)
             uint32_t bin = 0;   // src/dfire.rs:336-337 as a count of the steps passed
@@ -721,11 +832,39 @@ __device__ __forceinline__ uint32_t bm_recheck(BmArgs *T, const unsigned char *l
     const TiledBox box = T->m.rec_sub[(size_t)RT * 8 + b];
     const float cbx = 0.5f * (box.lox + box.hix), cby = 0.5f * (box.loy + box.hiy), cbz = 0.5f * (box.loz + box.hiz);
     const Affine A{a0.x, a0.y, a0.z, a0.w - cbx, a1.x, a1.y, a1.z, a1.w - cby, a2.x, a2.y, a2.z, a2.w - cbz};
+    // ANM: the pose's amplitudes, and the deformation of an atom as the batch forms it (LD_BM_FLEX_ASM)
+    const bool anm = T->amp != nullptr;
+    float amp_rec[kBmMaxModes], amp_lig[kBmMaxModes];
+    bool wild = false;
+#pragma unroll
+    for (int k = 0; k < kBmMaxModes; k++) amp_rec[k] = amp_lig[k] = 0.f;
+    if (anm) {
+        const float *am = T->amp + (size_t)row * kBmAmpFloats;
+#pragma unroll
+        for (int k = 0; k < kBmMaxModes; k++) {
+            amp_rec[k] = am[k];
+            amp_lig[k] = am[kBmMaxModes + k];
+        }
+        wild = am[20] != 0.f;
+    }
+    auto flexed = [&](const float *modes, const float *amps, int atom, int c) {   // modes: a subtile's kBmModeFloats (BmModel)
+        const float *m = modes + ((atom >> 1) * 3 + c) * kBmMaxModes * 2 + (atom & 1);
+        float d = amps[0] * m[0];   // (LD_BM_FLEX_ASM: a product, then nine fused multiply-adds)
+#pragma unroll
+        for (int k = 1; k < kBmMaxModes; k++) d = __builtin_fmaf(amps[k], m[2 * k], d);
+        return d;
+    };
     float lx[8], ly[8], lz[8], l2[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const float4 L = reinterpret_cast<const float4 *>(T->m.lig_local)[ls * 8 + i];
         bm_apply(A, L.x, L.y, L.z, lx[i], ly[i], lz[i]);
+        if (anm) {
+            const float *lm = T->m.lig_modes_f32 + (size_t)ls * kBmModeFloats;
+            lx[i] += flexed(lm, amp_lig, i, 0);
+            ly[i] += flexed(lm, amp_lig, i, 1);
+            lz[i] += flexed(lm, amp_lig, i, 2);
+        }
         l2[i] = __builtin_fmaf(lx[i], lx[i], __builtin_fmaf(ly[i], ly[i], lz[i] * lz[i]));
     }
     const float *rec = reinterpret_cast<const float *>(T->m.rec_pairs + (size_t)RT * 32 + b * 4);   // 4 records: x0 x1 y0 y1 z0 z1 . .
@@ -735,14 +874,20 @@ __device__ __forceinline__ uint32_t bm_recheck(BmArgs *T, const unsigned char *l
     for (int q = 0; q < 4; q++) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const float x = rec[q * 8 + h] - cbx, y = rec[q * 8 + 2 + h] - cby, z = rec[q * 8 + 4 + h] - cbz;
+            float x = rec[q * 8 + h] - cbx, y = rec[q * 8 + 2 + h] - cby, z = rec[q * 8 + 4 + h] - cbz;
+            if (anm) {   // (the batch: fma(1/2, 2 (r - c), d) = (r - c) + d, rounded once)
+                const float *rm = T->m.rec_modes_f32 + ((size_t)RT * 8 + (size_t)b) * kBmModeFloats;
+                x += flexed(rm, amp_rec, 2 * q + h, 0);
+                y += flexed(rm, amp_rec, 2 * q + h, 1);
+                z += flexed(rm, amp_rec, 2 * q + h, 2);
+            }
             const float Rs = __builtin_fmaf(-x, x, __builtin_fmaf(-y, y, __builtin_fmaf(-z, z, seed)));
             const float Rx = x * 2.f, Ry = y * 2.f, Rz = z * 2.f;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const uint32_t cell = bm_cell(Rs, Rz, Ry, Rx, l2[i], lz[i], ly[i], lx[i]);
                 const uint32_t code = lut[cell];
-                const bool hit = act && (code == kBmFlagged || (near_code != 0xffffffffu && code <= near_code));
+                const bool hit = act && (wild || code == kBmFlagged || (near_code != 0xffffffffu && code <= near_code));   // (a wild pose: every pair, the exact path decides)
                 const unsigned long long m = __ballot(hit);
                 if (hit) {
                     const uint32_t at = n_pairs + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -757,10 +902,10 @@ __device__ __forceinline__ uint32_t bm_recheck(BmArgs *T, const unsigned char *l
 }
 
 // DEBUG: per-wave phase timers (LIGHTDOCK_BM_DEBUG) -- the production instantiation carries none.
-template <bool DEBUG>
+template <bool DEBUG, bool ANM>
 __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(const BmLaunch launch_arguments) {
     BmArgs *T = LD_BM_ARGS;
-    __shared__ __attribute__((aligned(16))) BmShared S;   // the kernel's only LDS object: at LDS address 0
+    __shared__ __attribute__((aligned(16))) BmSharedT<ANM> S;   // the kernel's only LDS object: at LDS address 0
     // The batch code (dfire_bm_batch.inc) reads the LUT at `cell` and a cube row at `code + a constant of the instruction`: both
     // assume S at LDS address 0 with the LUT first.  Another __shared__ object or a different placement would make it read wrong
     // codes silently: trap instead (the compiler folds the test away when the address is the 0 it assigns today).  The block also
@@ -776,7 +921,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         const uint8_t *lut = T->count_mode ? T->m.lut_full : T->m.lut;
         for (int i = tid; i < kBmLutBytes / 16; i += kBmWaves * 64) reinterpret_cast<uint4 *>(S.lut)[i] = reinterpret_cast<const uint4 *>(lut)[i];
     }
-    BmWaveShared &WS = S.w[wave];
+    BmWaveSharedT<ANM> &WS = S.w[wave];
     __syncthreads();
     const uint32_t n_jobs = T->job_count[3];
     const bool wide_rows = T->n_poses > 65536;   // (a pass of more than 2^16 rows: a GSO over hundreds of swarms)
@@ -869,6 +1014,10 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 LocZ[p2] = v2f{from(16 + 2 * p2), from(17 + 2 * p2)};
             }
         }
+        if (ANM) {   // the job's ligand subtile's modes -> LDS (240 floats: 60 lanes x 16 bytes)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous job's last reads of them are done
+            if (lane < kBmModeFloats / 4) reinterpret_cast<float4 *>(WS.modes)[lane] = reinterpret_cast<const float4 *>(T->m.lig_modes_f32 + (size_t)ls * kBmModeFloats)[lane];
+        }
         // table rows of a block -> LDS by LDS-DMA: an instruction copies 5 rows, lane = (row of the five, one of its 11 pieces of
         // 16 bytes) -- the lane's two numbers are the same for every instruction, 55 lanes take part (piece p of an instruction
         // lands at its LDS address + 16 p: five rows of 176 bytes, contiguous).  The lane keeps the row block of ligand atom
@@ -932,7 +1081,12 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 LD_BM_DMA_ASM(dma_exec, dma_tmp, dma_rowsel, row_src, dma_piece, table_rows, cube_lds, 0x007fffffffffffffull, 0x00000fffffffffffull);
 #endif
             }
+            if (ANM) {   // the block's receptor subtile's modes -> LDS, behind the job's ligand modes
+                if (lane < kBmModeFloats / 4)
+                    reinterpret_cast<float4 *>(WS.modes + kBmModeFloats)[lane] = reinterpret_cast<const float4 *>(T->m.rec_modes_f32 + ((size_t)RT * 8 + (size_t)b) * kBmModeFloats)[lane];
+            }
             const bool tracked = lig_tracked || __builtin_amdgcn_readlane((int)my_tracked, b) != 0;
+            constexpr float seed = (float)kBmCellZero + 0.5f;
             // ---- the job's entries that hold block (a, b), in entry order (all 16 chunks' bytes in flight, then the ballots)
             uint32_t n_items = 0;
             {
@@ -957,6 +1111,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 float4 a0, a1, a2;   // the entry's affine map
                 long long prev;      // the entry's partial of this row so far
                 uint32_t item, row;
+                float4 amp[ANM ? kBmAmpFloats / 4 : 1];   // ANM: the pose's amplitudes, receptor's then ligand's; [20] != 0: a wild pose
             };
             // The way from a batch's place in the item list to its loads goes through LDS twice -- the item, then the entry's row of
             // the pass --: looked up when the loads were due, that was two LDS round trips at the head of every batch, with the
@@ -994,6 +1149,11 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 L.a0 = ap[0];
                 L.a1 = ap[1];
                 L.a2 = ap[2];
+                if (ANM) {
+                    const float4 *am = reinterpret_cast<const float4 *>(T->amp) + (size_t)row * (kBmAmpFloats / 4);
+#pragma unroll
+                    for (int k = 0; k < kBmAmpFloats / 4; k++) L.amp[k] = am[k];
+                }
                 L.prev = 0;
 #ifndef LD_BM_DIAG_NO_PARTIAL
                 if (!(item & 0x8000u)) L.prev = my_partial[item & 0x3ffu];
@@ -1048,9 +1208,45 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 const v2f A0xy{cur.a0.x, cur.a0.y}, A0zw{cur.a0.z, cur.a0.w - cbx}, A1xy{cur.a1.x, cur.a1.y}, A1zw{cur.a1.z, cur.a1.w - cby};
                 const v2f A2xy{cur.a2.x, cur.a2.y}, A2zw{cur.a2.z, cur.a2.w - cbz};
                 v2f LX[4], LY[4], LZ[4], L2[4];   // atoms (2p, 2p + 1): l - c and |l - c|^2
+                v2f fRs[4], fRz[4], fRy[4], fRx[4];   // ANM: the receptor subtile's operands of THIS lane's pose
+                bool wild = false;
+                if constexpr (!ANM) {
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    LD_BM_POSE_ASM(LX[p], LY[p], LZ[p], L2[p], A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, LocX[p], LocY[p], LocZ[p]);
+                    for (int p = 0; p < 4; p++) {
+                        LD_BM_POSE_ASM(LX[p], LY[p], LZ[p], L2[p], A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, LocX[p], LocY[p], LocZ[p]);
+                    }
+                } else {
+                    // Both subtiles flex with the lane's pose (src/dfire.rs:288-320): atom += sum_k amplitude_k x mode_k, in the receptor's
+                    // frame.  The modes of the two subtiles lie in LDS in the order they are read here -- per pair of atoms and
+                    // coordinate ten values a pair, two modes per 16-byte broadcast read --, the amplitudes came with the map; a
+                    // packed multiply-add per mode and pair of atoms, the amplitude's half picked by the operand select.
+                    const v2f *amp2 = reinterpret_cast<const v2f *>(cur.amp);   // [0..4] the receptor's amplitudes two by two, [5..9] the ligand's
+                    wild = reinterpret_cast<const float *>(cur.amp)[20] != 0.f;
+                    const uint32_t modes_lds = (uint32_t)(uintptr_t)WS.modes;
+                    {
+                        v2f D[12];   // the ligand subtile's deformation: atoms (2p, 2p + 1), coordinate c at [3 p + c] (LD_BM_FLEX_ASM, dfire_bm_batch.inc)
+                        LD_BM_FLEX_ASM(D, (amp2 + kBmMaxModes / 2), modes_lds);
+#pragma unroll
+                        for (int p = 0; p < 4; p++) {
+                            LD_BM_POSE_FLEX_ASM(LX[p], LY[p], LZ[p], L2[p], A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, LocX[p], LocY[p], LocZ[p], D[3 * p], D[3 * p + 1], D[3 * p + 2]);
+                        }
+                    }
+                    // the receptor subtile: (r - c) = Rx / 2 exactly, + the lane's deformation, then the operands as the rigid form's table
+                    // holds them: seed - |r - c|^2 and 2 (r - c)
+                    {
+                        v2f D[12];
+                        LD_BM_FLEX_ASM(D, amp2, modes_lds + (uint32_t)(kBmModeFloats * sizeof(float)));
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const v2f half{0.5f, 0.5f}, two{2.f, 2.f};
+                            const v2f x = __builtin_elementwise_fma(half, Rx[q], D[3 * q]), y = __builtin_elementwise_fma(half, Ry[q], D[3 * q + 1]);
+                            const v2f z = __builtin_elementwise_fma(half, Rz[q], D[3 * q + 2]);
+                            fRs[q] = __builtin_elementwise_fma(-x, x, __builtin_elementwise_fma(-y, y, __builtin_elementwise_fma(-z, z, v2f{seed, seed})));
+                            fRx[q] = x * two;
+                            fRy[q] = y * two;
+                            fRz[q] = z * two;
+                        }
+                    }
                 }
                 // The batch's 64 pairs: dfire_bm_batch.inc (generated, tools/gen_bm_batch_asm.py).  Fixed-point sum: table
                 // values are integers (2^-k units, exact adds in any order); a flagged cell's slot holds the row's marker.
@@ -1091,7 +1287,11 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                     LD_BM_BATCH_ASM_V(acc0, acc1, vRs, vRz, vRy, vRx, L2, LZ, LY, LX, kCube);
                 }
 #elif !defined(LD_BM_DIAG_NO_PAIRS)
-                LD_BM_BATCH_ASM(acc0, acc1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX, kCube);
+                if constexpr (ANM) {
+                    LD_BM_BATCH_ASM_V(acc0, acc1, fRs, fRz, fRy, fRx, L2, LZ, LY, LX, kCube);
+                } else {
+                    LD_BM_BATCH_ASM(acc0, acc1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX, kCube);
+                }
 #else
                 asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(L2[0]), "v"(L2[1]), "v"(L2[2]), "v"(L2[3]), "v"(LX[0]), "v"(LY[0]), "v"(LZ[0]), "s"(Rs[0]), "s"(Rx[3]));
 #endif
@@ -1104,8 +1304,10 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 const unsigned long long both = acc0 + acc1;
                 const long long part = (long long)(((unsigned long long)((uint32_t)(both >> 32) - ((uint32_t)(mark0 + mark1) << kHiShift)) << 32) | (uint32_t)both);
                 const int mark = mark0 | mark1;   // (one of them 0: the other's value)
-                const bool any_flagged = valid && mark != 0;
-                const bool one = any_flagged && (mark0 == 0 || mark1 == 0) && mark >= 64 && mark < 128, several = any_flagged && !one;
+                // (ANM: a wild pose -- amplitudes beyond what the f32 arithmetic's error bound covers -- sends its whole block to the exact
+                // path through the list of (entry, block) items, and nothing of what it summed here counts)
+                const bool any_flagged = valid && (mark != 0 || wild);
+                const bool one = any_flagged && !wild && (mark0 == 0 || mark1 == 0) && mark >= 64 && mark < 128, several = any_flagged && !one;
                 const unsigned long long m1 = __ballot(one), m2 = __ballot(several);
                 // the lane's one pair in a flagged cell (0.1 % of all pairs; some lane of nearly every batch has one): the exact path.
                 // Like the lane's sum, the item leaves at the start of the NEXT batch (flush_pending): stored here, just before the
@@ -1127,7 +1329,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 // The lane's sum goes out at the start of the NEXT batch (flush_pending): memory operations complete in order, and
                 // the wait for the next batch's loads at the loop's top would wait for a store or atomic issued here, just before it,
                 // as well -- a round trip to the L2 per batch.  Issued in front of the following loads, it has a whole batch to complete.
-                pending_val = cur.prev + part;
+                pending_val = cur.prev + (wild ? 0ll : part);
                 pending_item = valid ? cur.item : 0xffffffffu;
                 pending_row = cur.row;
             };
@@ -1143,6 +1345,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 // a write or two, waited for the first of the loads just issued: a round trip to the L2 in every batch.)
                 asm volatile("" :: "v"(next.a0.x), "v"(next.a0.y), "v"(next.a0.z), "v"(next.a0.w), "v"(next.a1.x), "v"(next.a1.y), "v"(next.a1.z), "v"(next.a1.w),
                              "v"(next.a2.x), "v"(next.a2.y), "v"(next.a2.z), "v"(next.a2.w), "v"(next.prev));
+                if constexpr (ANM) asm volatile("" :: "v"(next.amp[0].x), "v"(next.amp[1].x), "v"(next.amp[2].x), "v"(next.amp[3].x), "v"(next.amp[4].x), "v"(next.amp[5].x));
                 const BatchLoads cur = next;
 #ifdef LD_BM_DIAG_WAIT   // (diagnostic builds: the drain timer holds the time a wave waits at the head of its batches for their loads)
                 if (DEBUG) dbg_t_drain += now() - dbg_tb;
@@ -1278,14 +1481,20 @@ hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream) {
     const size_t per_cu = std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 512)));
     const size_t cus = t.pairs_groups > 0 ? (size_t)t.pairs_groups : 256;
     const size_t blocks = std::min<size_t>(((t.n_poses + kBmCullPoses - 1) / kBmCullPoses * (size_t)t.m.lig.n_tiles + kBmCullWaves - 1) / kBmCullWaves, cus * per_cu);
+    const bool anm = t.amp != nullptr, count = t.tile_tested != nullptr;
+    const void *kernel = anm ? (count ? reinterpret_cast<const void *>(&dfire_bm_cull<true, true>) : reinterpret_cast<const void *>(&dfire_bm_cull<false, true>))
+                             : (count ? reinterpret_cast<const void *>(&dfire_bm_cull<true, false>) : reinterpret_cast<const void *>(&dfire_bm_cull<false, false>));
     if (lds > 64 * 1024) {   // (a receptor of more than ~100 tiles)
-        const hipError_t e = t.tile_tested != nullptr
-            ? hipFuncSetAttribute(reinterpret_cast<const void *>(&dfire_bm_cull<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-            : hipFuncSetAttribute(reinterpret_cast<const void *>(&dfire_bm_cull<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (t.tile_tested != nullptr) hipLaunchKernelGGL((dfire_bm_cull<true>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
-    else hipLaunchKernelGGL((dfire_bm_cull<false>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
+    if (anm) {
+        if (count) hipLaunchKernelGGL((dfire_bm_cull<true, true>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
+        else hipLaunchKernelGGL((dfire_bm_cull<false, true>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
+    } else {
+        if (count) hipLaunchKernelGGL((dfire_bm_cull<true, false>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
+        else hipLaunchKernelGGL((dfire_bm_cull<false, false>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
+    }
     return hipGetLastError();
 }
 
@@ -1303,8 +1512,13 @@ hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
     hipLaunchKernelGGL(dfire_bm_census, dim3(128), dim3(kBmOrderWaves * 64), 0, stream, t);
     hipLaunchKernelGGL(dfire_bm_order, dim3(1), dim3(kBmOrderWaves * 64), 0, stream, t);
     const unsigned groups = bm_pairs_groups(t);
-    if (t.debug != nullptr) hipLaunchKernelGGL((dfire_bm_pairs<true>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
-    else hipLaunchKernelGGL((dfire_bm_pairs<false>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
+    if (t.amp != nullptr) {   // molecules that flex per pose
+        if (t.debug != nullptr) hipLaunchKernelGGL((dfire_bm_pairs<true, true>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
+        else hipLaunchKernelGGL((dfire_bm_pairs<false, true>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
+    } else {
+        if (t.debug != nullptr) hipLaunchKernelGGL((dfire_bm_pairs<true, false>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
+        else hipLaunchKernelGGL((dfire_bm_pairs<false, false>), dim3(groups), dim3(kBmWaves * 64), 0, stream, t);
+    }
     return hipGetLastError();
 }
 

@@ -71,6 +71,12 @@ constexpr int kBmMarkerShift = 51;           // a lane keeps two sums of 32 pair
 constexpr int kBmJobRows = 8;                // a job = (tile pair, part of its entries, ligand subtile a): the blocks (a, 0..7); one partial sum per (entry, a)
 constexpr int kBmPartEntries = 1024;         // entries of a tile pair in one job
 constexpr int kBmOpsFloats = 36;             // BmModel::rec_ops: Rs[4][2], Rz[4][2], Ry[4][2], Rx[4][2], cx, cy, cz, 0
+constexpr int kBmMaxModes = 10;              // normal modes per molecule the ANM form of the path takes (the reference's examples: 10 + 10, src/dfire.rs:288-320)
+constexpr int kBmModeFloats = 8 * 3 * kBmMaxModes;   // a subtile's modes as a batch reads them: ((atom pair p * 3 + coordinate) * kBmMaxModes + mode) * 2 + atom of the pair
+constexpr int kBmAmpFloats = 24;             // a row's amplitudes as the pair kernel loads them: receptor modes 0..9, ligand modes 10..19, [20] != 0: a WILD pose
+constexpr int kBmAnmPartEntries = 512;       // entries of a tile pair in one job of the ANM form (its LDS holds two subtiles' modes where the other keeps 512 entries more)
+constexpr float kBmWildUnits = 256.0f;       // a pose whose amplitudes could move an atom further than this (record units: 32 A) is WILD: every pair of its
+                                             // blocks goes to the exact path (the f32 arithmetic's error bound covers deformations up to here)
 constexpr int kBmCubeRows = 64;              // table rows of a block: 8 ligand x 8 receptor atoms
 constexpr int kBmCubeBytes = kBmCubeRows * kBmRowBytes;
 constexpr int kBmTypes = 170;                // 169 DFIRE types + one all-zero type for padding atoms
@@ -126,6 +132,16 @@ struct BmModel {
     const uint32_t *rec_tindex = nullptr;       // tile order: tiled_rec_term (exact path reads the patch table)
     const int32_t *rec_slot = nullptr;
     int rec_flag_words = 0;
+    // DFIRE with normal modes (src/dfire.rs:288-320: both molecules flex per pose).  The block-major form: the receptor's boxes per
+    // pose from dfire_packed_prepare (BmLaunch::anm_sub / anm_tile), the ligand's atoms flexed by the culling kernel; a lane of a
+    // batch flexes its pose's 8 + 8 atoms itself -- the two subtiles' modes lie in LDS, the pose's amplitudes come with its map.
+    int anm_rec = 0, anm_lig = 0;               // modes of either molecule; 0 + 0: the rigid form
+    const float *rec_modes_f32 = nullptr;       // [rec subtiles][kBmModeFloats]: kappa x the modes, f32, in the batch's order (absent modes 0)
+    const float *lig_modes_f32 = nullptr;       // [lig subtiles][kBmModeFloats]
+    const float *lig_modes_atom = nullptr;      // [lig atoms (tile order)][32]: the same modes per atom, [mode][x y z] (the culling kernel: lane = atom)
+    const double *rec_modes = nullptr;          // f64 [mode][xyz][rec_pad]: the exact path (src/dfire.rs:304-320)
+    size_t rec_pad = 0;
+    float rec_mode_reach[kBmMaxModes] = {}, lig_mode_reach[kBmMaxModes] = {};   // kappa x the largest |mode vector| of an atom, per mode: sum |amplitude| x this bounds a pose's deformation
     // ligand
     TiledLigand lig;                            // f64, tile order (exact path, overflow tiles)
     const double *lig_exact = nullptr, *rec_exact = nullptr;   // [atom][4]: x, y, z (f64) and {table term, interface-flag slot}: what the exact path reads of an atom, in two loads
@@ -161,6 +177,10 @@ struct BmLaunch {
     size_t cap = 0;                        // entries per tile pair the workspace has room for (>= n_poses)
     int count_mode = 0;                    // 1: a counting launch -- full LUT, rows of ones, the sums are in-cutoff pair counts (-> count_partial)
     // workspace of the pass; "row" = row of the pass
+    float *amp = nullptr;                  // ANM: [row][kBmAmpFloats] f32 amplitudes (dfire_bm_pose), or nullptr
+    const TiledBox *anm_sub = nullptr;     // ANM: the receptor's subtile boxes per POSE [pose][n_rt * 8] (dfire_packed_prepare, the kappa = 8 frame) ...
+    const TiledBox *anm_tile = nullptr;    // ... and tile boxes [pose][n_rt]
+    uint32_t part_cap = 0;                 // entries per part at most (kBmPartEntries, or kBmAnmPartEntries for the ANM form)
     float *rt = nullptr;                   // [row][12]: the pose as an f32 affine map
     double *rt_exact = nullptr;            // [row][8]: the pose as the exact path reads it: t, q (f64, the launch's own numbers), its index in the launch
     uint32_t *tp_count = nullptr;          // [n_tile_pairs], zeroed per launch
@@ -192,9 +212,9 @@ struct BmLaunch {
 // Bound on |D''_f32 - 64 d2 - 1/2| (LUT cells) for a ligand atom posed by the f32 affine map and a receptor record,
 // both inside `ubound` (record units), pairs within 1100 units of 4 d2; `lig_extent` = largest |local coordinate| of
 // the ligand (angstrom).  Twice the derived bound.
-double dfire_bm_error_bound(double ubound, double lig_extent);
+double dfire_bm_error_bound(double ubound, double lig_extent, bool anm = false);   // anm: molecules that flex (poses that are not wild)
 // Largest distance (record units) between an f32-posed ligand atom inside ubound and its exactly posed position.
-double dfire_bm_pose_error(double ubound, double lig_extent);
+double dfire_bm_pose_error(double ubound, double lig_extent, bool anm = false);
 
 size_t bm_pairs_lds_bytes();
 hipError_t launch_bm_pose(const BmLaunch &t, hipStream_t stream);

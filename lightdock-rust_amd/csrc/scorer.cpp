@@ -363,6 +363,7 @@ void Scorer::upload_tiled_molecule(const ld_molecule &m, bool is_receptor, Tiled
             }
         out.modes = arena_.upload(modes);
         out.num_anm = (int)m.num_anm;
+        out.hmodes = std::move(modes);
     }
 }
 
@@ -629,16 +630,25 @@ void Scorer::build_packed(const ld_scorer_desc &desc) {
 // ---------------------------------------------------------------------------------------
 // Block-major DFIRE path (kernels/dfire_bm.hpp)
 // ---------------------------------------------------------------------------------------
-double dfire_bm_pose_error(double ubound, double lig_extent) {
+// What flexing adds to a posed atom's f32 coordinate (record units), for poses that are not WILD (deformations below
+// kBmWildUnits = W per coordinate): the ten terms amplitude x mode with both factors rounded to f32 (2^-23 W together), and the
+// ten fma roundings of partial sums below `magnitude`.
+static double bm_flex_error(double magnitude) {
+    const double W = kBmWildUnits;
+    return std::ldexp(W, -23) + 10.0 * std::ldexp(1.0, (int)std::floor(std::log2(magnitude)) - 24);
+}
+
+double dfire_bm_pose_error(double ubound, double lig_extent, bool anm) {
     // u = fl32(kappa R) x_f32 + fl32(kappa (t - c)), three fmas.  Per coordinate, in record units:
     //   matrix rounding            3 * 2^-24 * kappa * extent      (|kappa R_ij| <= kappa, |x| <= extent)
     //   local coordinate rounding  3 * kappa * 2^-24 * extent
     //   translation rounding + the three fma roundings (partial sums below 2 U): 4 * 2^-24 U
-    const double e = std::ldexp(6.0 * kBmKappa * lig_extent, -24) + std::ldexp(ubound, -22);
+    double e = std::ldexp(6.0 * kBmKappa * lig_extent, -24) + std::ldexp(ubound, -22);
+    if (anm) e += bm_flex_error(2.0 * ubound + kBmWildUnits);   // the culling kernel: mode by mode onto the posed coordinate
     return std::sqrt(3.0) * e;
 }
 
-double dfire_bm_error_bound(double ubound, double lig_extent) {
+double dfire_bm_error_bound(double ubound, double lig_extent, bool anm) {
     // What dfire_bm_pairs computes: coordinates relative to the centre c of the receptor subtile's box (an f32 constant),
     //   D'' = (|r - c|^2 + seed) + |l - c|^2 - 2 (r - c) . (l - c)
     // in f32: 3 + 3 operations for the two squares, one add, three fmas.  For the f32 coordinates this is |l - r|^2 + seed
@@ -649,11 +659,16 @@ double dfire_bm_error_bound(double ubound, double lig_extent) {
                          + 2.0 * half_ulp(ubound)               // of the stored translation, and of translation - c
                          + 3.0 * half_ulp(ubound / 2 + reach);  // of the three fmas: partial sums below |translation - c| + |kappa R x|
     const double e_rec = half_ulp(ubound) + half_ulp(128.0);    // the record's rounding, and that of r - c
-    const double e_d = e_lig + e_rec;
+    double e_d = e_lig + e_rec;
+    // Molecules that flex (poses that are not WILD): either atom's deformation d = sum_k fl(a_k) fl(kappa m_k), ten fmas from 0
+    // (partial sums below W), then ONE rounded add onto the posed coordinate / onto r - c.
+    const double W = kBmWildUnits;
+    if (anm) e_d += 2.0 * bm_flex_error(W * 0.999) + half_ulp(ubound / 2 + reach + W) + half_ulp(128.0 + W);
     const double span = std::sqrt(3.0 * 1100.0 * kBmCells);     // |du| + |dv| + |dw| <= sqrt(3) |d|, pairs within 1100 units of 4 d2
     // The ten roundings of the distance arithmetic: every operand and partial sum of such a pair is below 2^17
     // (|l - c| <= 16.6 A + a subtile's half extent < 45 A = 362 record units; the seed carries the LUT's offset, < 2^15).
-    const double eps = 2.0 * e_d * span + 3.0 * e_d * e_d + 10.0 * half_ulp(131072.0 * 0.999);
+    // (flexing: r - c + d up to 128 + W, l - c up to that + the cutoff's 133 units -- squares below 2^19)
+    const double eps = 2.0 * e_d * span + 3.0 * e_d * e_d + 10.0 * half_ulp((anm ? 524288.0 : 131072.0) * 0.999);
     return 2.0 * eps;  // twice the bound, LUT cells
 }
 
@@ -792,9 +807,16 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     // (LIGHTDOCK_BM_DIAG_IGNORE_ANM=1: timing experiments only -- the block-major kernels on an ANM complex as if it were rigid, wrong sums)
     const char *ignore_anm = std::getenv("LIGHTDOCK_BM_DIAG_IGNORE_ANM");
     const bool diag_rigid = ignore_anm && std::atoi(ignore_anm) == 1;
-    if (!diag_rigid && use_anm_ && (desc.receptor.num_anm > 0 || desc.ligand.num_anm > 0)) return;
-    if (!diag_rigid && rec_anm_per_pose_) return;
     const TiledSoA &rec = tiled_rec_soa_, &lig = tiled_lig_soa_;
+    // Molecules that flex per pose (src/dfire.rs:288-320): the ANM form of the kernels, for up to kBmMaxModes modes a molecule and a
+    // receptor below 8192 atoms (the fixed-point scale's reach count is then the atom count whatever the deformation).
+    // LIGHTDOCK_BM_ANM=0: such complexes stay with the pose-major kernels (A/B, tests).
+    const bool anm = !diag_rigid && use_anm_ && (rec.num_anm > 0 || lig.num_anm > 0);
+    if (anm) {
+        const char *e = std::getenv("LIGHTDOCK_BM_ANM");
+        if (e && std::atoi(e) == 0) return;
+        if (rec.num_anm > kBmMaxModes || lig.num_anm > kBmMaxModes || rec.n_real >= 8192) return;
+    }
     if (rec.n_tiles > 1024 || lig.n_tiles > 1024) return;  // an item of the exact path names its atoms in 16 bits each
     if (bm_cull_lds_bytes(rec.n_tiles) + 1024 > kBmLdsPerCu) return;  // the culling kernel keeps every receptor box in LDS: ~430 tiles at most
     // Table values reach a pose's sum as 64-bit fixed point (dfire_bm.hpp): a table that could overflow it or that the scale
@@ -808,11 +830,12 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     double centre[3], half;
     frame_of_receptor(desc.receptor, centre, &half);
     // The frame holds the receptor's box + 16 A: a ligand atom outside it is beyond the cutoff of every receptor atom.
+    // (flexing: a receptor atom of a pose that is not WILD moves less than kBmWildUnits)
     double ubound = 128.0;
-    while (ubound < kBmKappa * (half + 16.5)) ubound *= 2.0;
+    while (ubound < kBmKappa * (half + 16.5) + (anm ? (double)kBmWildUnits : 0.0)) ubound *= 2.0;
     double extent = 0.0;
     for (size_t i = 0; i < desc.ligand.n_atoms * 3; i++) extent = std::max(extent, std::fabs(desc.ligand.coordinates[i]));
-    double eps = dfire_bm_error_bound(ubound, extent);  // LUT cells
+    double eps = dfire_bm_error_bound(ubound, extent, anm);  // LUT cells
     if (const char *e = std::getenv("LIGHTDOCK_PACKED_EPS_SCALE")) {  // test hook: results must not depend on it
         const double f = std::atof(e);
         if (f >= 1.0 && f <= 1000.0) eps *= f;
@@ -833,7 +856,7 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     M.cy = centre[1];
     M.cz = centre[2];
     M.ubound = (float)ubound;
-    M.box_pad = std::nextafter((float)(2.0 * dfire_bm_pose_error(ubound, extent)), INFINITY);
+    M.box_pad = std::nextafter((float)(2.0 * dfire_bm_pose_error(ubound, extent, anm)), INFINITY);
     M.table = tiled_.table;
     M.iface_scaled = 4.0 * pair_.iface_d2;
     {
@@ -900,6 +923,40 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
             }
             M.rec_ops = arena_.upload(ops);
         }
+    }
+    if (anm) {   // the modes as the kernels read them: kappa x, f32 (BmModel)
+        M.anm_rec = rec.num_anm;
+        M.anm_lig = lig.num_anm;
+        M.rec_modes = rec.modes;
+        M.rec_pad = (size_t)rec.n_tiles * 64;
+        auto tables = [&](const TiledSoA &m, std::vector<float> &by_subtile, std::vector<float> *by_atom, float *reach) {
+            const size_t pad = (size_t)m.n_tiles * 64;
+            by_subtile.assign(pad / 8 * (size_t)kBmModeFloats, 0.f);
+            if (by_atom) by_atom->assign(pad * 32, 0.f);
+            for (int k = 0; k < kBmMaxModes; k++) reach[k] = 0.f;
+            for (int k = 0; k < m.num_anm; k++) {
+                double longest = 0.0;
+                for (size_t i = 0; i < pad; i++) {
+                    double n2 = 0.0;
+                    for (int c = 0; c < 3; c++) {
+                        const double v = m.hmodes[((size_t)k * 3 + c) * pad + i];
+                        const float f = (float)(kBmKappa * v);
+                        by_subtile[(i / 8) * (size_t)kBmModeFloats + ((((i % 8) / 2) * 3 + c) * (size_t)kBmMaxModes + k) * 2 + (i & 1)] = f;
+                        if (by_atom) (*by_atom)[i * 32 + 3 * (size_t)k + c] = f;
+                        n2 += v * v;
+                    }
+                    longest = std::max(longest, std::sqrt(n2));
+                }
+                // (not finite: every pose with a non-zero amplitude of this mode is wild; NaN stays NaN and fails the kernel's comparison)
+                reach[k] = std::nextafter((float)(kBmKappa * longest * 1.001), INFINITY);
+            }
+        };
+        std::vector<float> rsub, lsub, latom;
+        tables(rec, rsub, nullptr, M.rec_mode_reach);
+        tables(lig, lsub, &latom, M.lig_mode_reach);
+        M.rec_modes_f32 = arena_.upload(rsub);
+        M.lig_modes_f32 = arena_.upload(lsub);
+        M.lig_modes_atom = arena_.upload(latom);
     }
     const uint32_t kPad = std::numeric_limits<uint32_t>::max();
     {   // per atom: where its type's rows / column sit in the row table; padding atoms take the all-zero type
@@ -1043,6 +1100,22 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         t.tested_partial = static_cast<uint32_t *>(ws_tested_.ptr);
         t.exact_partial = static_cast<uint32_t *>(ws_exact_.ptr);
     }
+    const bool anm = bm_.anm_rec + bm_.anm_lig > 0;
+    if (anm) {   // every pose's receptor boxes in the block-major frame (src/dfire.rs:304-320 moves the receptor's atoms per pose)
+        PackedPrepareLaunch pr = packed_prepare_launch(d_poses, stride, d_active, n);
+        pr.cx = bm_.cx;
+        pr.cy = bm_.cy;
+        pr.cz = bm_.cz;
+        pr.kappa = kBmKappa;
+        pr.ubound = bm_.ubound;
+        pr.pairs_out = nullptr;   // (the boxes only)
+        pr.sub_out = static_cast<TiledBox *>(ws_rec_sub_.ptr);
+        pr.tile_out = static_cast<TiledBox *>(ws_rec_tile_.ptr);
+        hip_check(launch_packed_prepare(pr, stream_), "launch dfire_packed_prepare");
+        t.anm_sub = pr.sub_out;
+        t.anm_tile = pr.tile_out;
+        t.part_cap = (uint32_t)kBmAnmPartEntries;
+    }
     const char *dbg = std::getenv("LIGHTDOCK_BM_DEBUG");
     if (dbg) {
         ws_bm_debug_.reserve(waves * 8 * sizeof(unsigned long long));
@@ -1076,6 +1149,7 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         t.ent_partial = static_cast<long long *>(ws_bm_ent_partial_.ptr) + w * waves * kBmPartEntries;
         t.tile_sum = static_cast<long long *>(ws_bm_tile_sum_.ptr) + w * cap * n_lt;
         t.exact_fix = static_cast<long long *>(ws_bm_exact_fix_.ptr) + w * cap;
+        t.amp = anm ? static_cast<float *>(ws_bm_amp_.ptr) + w * cap * kBmAmpFloats : nullptr;
         // With pair counts wanted the sequence runs twice: first as a counting launch (the same kernels over rows of ones and the
         // full LUT: the sums are the in-cutoff pair counts), then for the energies.
         for (int mode = counts ? 1 : 0; mode >= 0; mode--) {
@@ -1171,7 +1245,7 @@ Scorer::~Scorer() {
     ws_rec_pairs_.release();
     ws_exact_.release();
     for (DeviceBuffer *b : {&ws_bm_rt_, &ws_bm_tp_count_, &ws_bm_ent_row_, &ws_bm_jobs_, &ws_bm_job_cost_, &ws_bm_job_order_, &ws_bm_ent_mask_, &ws_bm_queue_, &ws_bm_ent_partial_, &ws_bm_tile_sum_,
-                            &ws_bm_tile_tested_, &ws_bm_exact_fix_, &ws_bm_exact_pairs_})
+                            &ws_bm_tile_tested_, &ws_bm_exact_fix_, &ws_bm_exact_pairs_, &ws_bm_amp_})
         b->release();
     ws_poses_.release();
     ws_energies_.release();
@@ -1182,7 +1256,7 @@ uint64_t Scorer::workspace_generation() const {
            ws_rec_atoms_.generation + ws_rec_sub_.generation + ws_rec_tile_.generation + ws_rec_pairs_.generation + ws_bm_rt_.generation +
            ws_bm_tp_count_.generation + ws_bm_ent_row_.generation + ws_bm_jobs_.generation + ws_bm_job_cost_.generation + ws_bm_job_order_.generation + ws_bm_ent_mask_.generation + ws_bm_queue_.generation + ws_bm_ent_partial_.generation +
            ws_bm_tile_sum_.generation + ws_bm_tile_tested_.generation +
-           ws_bm_exact_fix_.generation + ws_bm_exact_pairs_.generation;
+           ws_bm_exact_fix_.generation + ws_bm_exact_pairs_.generation + ws_bm_amp_.generation;
 }
 
 void Scorer::reserve_workspace(size_t n_poses, bool counts) {
@@ -1211,6 +1285,11 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         ws_bm_ent_partial_.reserve(sets * waves * kBmPartEntries * sizeof(long long));   // per wave of dfire_bm_pairs: the partial sums of its current job (8 KB, L2 resident)
         ws_bm_tile_sum_.reserve(sets * cap * n_lt * sizeof(long long));
         ws_bm_exact_fix_.reserve(sets * cap * sizeof(long long));
+        if (bm_.anm_rec + bm_.anm_lig > 0) {   // the poses' amplitudes by row, and the receptor's boxes by pose
+            ws_bm_amp_.reserve(sets * cap * kBmAmpFloats * sizeof(float));
+            ws_rec_sub_.reserve(n_poses * n_rt * 8 * sizeof(TiledBox));
+            ws_rec_tile_.reserve(n_poses * n_rt * sizeof(TiledBox));
+        }
         if (counts) {
             ws_bm_tile_tested_.reserve(sets * cap * n_lt * sizeof(uint32_t));
             ws_bm_exact_pairs_.reserve(sets * cap * sizeof(uint32_t));
@@ -1225,7 +1304,7 @@ void Scorer::energy_batch_device(size_t n, const double *d_poses, size_t stride,
     if (stride < pose_len()) throw Error(LD_ERR_INVALID, "energy_batch: stride shorter than a pose row");
     // the list is the compacted form of the mask: the pair kernels walk the list, the tail kernel the mask
     if (d_list && (!d_active || !d_count)) throw Error(LD_ERR_INVALID, "energy_batch: a pose list needs its device-side count and the matching active mask");
-    if (use_tiled_ && rec_anm_per_pose_) {
+    if (use_tiled_ && rec_anm_per_pose_ && !use_bm_) {   // (the block-major path keeps a pose's receptor BOXES only: 36 bytes an atom less)
         // every pose carries its own deformed receptor image: bound that workspace (8 GiB) by
         // slicing very large batches; poses are independent, so the results do not change
         const size_t pad = (size_t)tiled_.rec.n_tiles * 64;

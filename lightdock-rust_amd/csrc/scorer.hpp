@@ -129,6 +129,7 @@ class Scorer {
         std::vector<double> hx, hy, hz;   // host copies, tile order (padding included)
         std::vector<uint32_t> htype;      // DFIRE type per slot of the tile order, 0xffffffff = padding
         std::vector<int32_t> hslot;       // interface-flag slot or -1
+        std::vector<double> hmodes;       // host copy of `modes`: [mode][xyz][padded atoms]
     };
     void upload_tiled_molecule(const ld_molecule &m, bool is_receptor, TiledSoA &out);
     PrepareReceptorLaunch prepare_launch(const double *poses, size_t stride, const uint8_t *active, size_t n) const;
@@ -150,7 +151,7 @@ class Scorer {
     const uint32_t *packed_lut_full_ = nullptr;  // the LUT without elided zero bins (counting launches)
     uint32_t packed_zero_bins_ = 0;
     DeviceBuffer ws_rec_pairs_, ws_exact_;
-    bool use_bm_ = false;      // DFIRE without ANM: the block-major path (kernels/dfire_bm.hpp) evaluates every batch
+    bool use_bm_ = false;      // DFIRE: the block-major path (kernels/dfire_bm.hpp) evaluates every batch
     BmModel bm_;
     TiledSoA tiled_lig_soa_;
     size_t bm_chunk_ = 0;      // poses per block-major pass (bounds the entry workspace)
@@ -161,7 +162,7 @@ class Scorer {
     hipEvent_t bm_fork_ = nullptr, bm_join_ = nullptr;
     int n_cus_ = 256;
     DeviceBuffer ws_bm_debug_, ws_bm_jobs_, ws_bm_job_cost_, ws_bm_job_order_, ws_bm_rt_, ws_bm_tp_count_, ws_bm_ent_row_, ws_bm_ent_mask_, ws_bm_queue_, ws_bm_ent_partial_, ws_bm_tile_sum_,
-        ws_bm_tile_tested_, ws_bm_exact_fix_, ws_bm_exact_pairs_;
+        ws_bm_tile_tested_, ws_bm_exact_fix_, ws_bm_exact_pairs_, ws_bm_amp_;
     TiledSoA tiled_rec_soa_;          // receptor in tile order (input of dfire_prepare_receptor)
     bool rec_anm_per_pose_ = false;   // receptor ANM: one receptor image per pose per launch
     DeviceBuffer ws_rec_atoms_, ws_rec_sub_, ws_rec_tile_;

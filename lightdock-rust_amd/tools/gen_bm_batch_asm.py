@@ -88,6 +88,48 @@ def pose_block():
     return lines, outs, ins
 
 
+def pose_flex_block():
+    """pose_block for molecules that flex (src/dfire.rs:288-301): the same three chains, then + (DX, DY, DZ) -- the deformation of the two
+    atoms, formed by the caller -- and only then |l|^2.  (R x + t') + d: the order bm_recheck repeats."""
+    lines, outs, ins = pose_block()
+    at = [i for i, l in enumerate(lines) if l.startswith("v_pk_mul_f32 %[l2]")][0]
+    lines = lines[:at] + ["v_pk_add_f32 %[lx], %[lx], %[dx]", "v_pk_add_f32 %[ly], %[ly], %[dy]", "v_pk_add_f32 %[lz], %[lz], %[dz]"] + lines[at:]
+    ins = ins + ['[dx] "v"(DX)', '[dy] "v"(DY)', '[dz] "v"(DZ)']
+    return lines, outs, ins
+
+
+def flex_block():
+    """The deformation of one subtile's 8 atoms for the lane's pose (src/dfire.rs:288-320): D[pc] = sum_k amplitude_k x mode_k of the
+    atoms (2p, 2p + 1)'s coordinate c, pc = 3 p + c -- twelve packed sums of ten terms.  The subtile's modes lie in LDS in this
+    order (BmModel: ((pc * 10 + k) * 2 + atom of the pair) floats), sixty 16-byte broadcast reads of two modes each; EIGHT are
+    kept in flight in the fixed registers v[220:251] (the batch's temporaries, free here), every wait counted.  (As C++ the
+    compiler, out of registers, issued each read, waited for it and only then multiplied: 120 LDS round trips a batch, and
+    the ANM form ran at 6.4 us a batch against the rigid form's 2.4.)  The first term is a product, the others fused
+    multiply-adds in mode order: bm_recheck repeats exactly this.  Operands: D0..D11 (outputs), A0..A4 (the molecule's
+    amplitudes two by two), MODES (VGPR: the LDS address of the subtile's modes)."""
+    RING, N = 8, 60
+    reg = lambda i: "v[%d:%d]" % (220 + 4 * (i % RING), 223 + 4 * (i % RING))
+    lo = lambda i: "v[%d:%d]" % (220 + 4 * (i % RING), 221 + 4 * (i % RING))
+    hi = lambda i: "v[%d:%d]" % (222 + 4 * (i % RING), 223 + 4 * (i % RING))
+    lines = ["ds_read_b128 %s, %%[modes] offset:%d" % (reg(i), 16 * i) for i in range(RING)]
+    for i in range(N):
+        issued = min(N, i + RING)
+        lines.append("s_waitcnt lgkmcnt(%d)" % (issued - i - 1))
+        pc, k2 = i // 5, i % 5
+        d, a = "%%[d%d]" % pc, "%%[a%d]" % k2
+        if k2 == 0:
+            lines.append("v_pk_mul_f32 %s, %s, %s op_sel:[0,0] op_sel_hi:[0,1]" % (d, a, lo(i)))
+        else:
+            lines.append("v_pk_fma_f32 %s, %s, %s, %s op_sel:[0,0,0] op_sel_hi:[0,1,1]" % (d, a, lo(i), d))
+        lines.append("v_pk_fma_f32 %s, %s, %s, %s op_sel:[1,0,0] op_sel_hi:[1,1,1]" % (d, a, hi(i), d))
+        if i + RING < N:
+            lines.append("ds_read_b128 %s, %%[modes] offset:%d" % (reg(i), 16 * (i + RING)))
+    outs = ['[d%d] "=&v"(D[%d])' % (k, k) for k in range(12)]
+    ins = ['[a%d] "v"(A[%d])' % (k, k) for k in range(5)] + ['[modes] "v"(MODES)']
+    clobbers = ['"v%d"' % r for r in range(220, 252)]
+    return lines, outs, ins, clobbers
+
+
 def dma_block():
     """A block's 64 table rows L2 -> LDS: 13 LDS-DMA instructions of five rows each (55 lanes: row of the five, one of the row's
     11 pieces of 16 bytes).  Lane r of SRC holds the table offset of row r; the lane that copies (row, piece) of instruction t
@@ -154,6 +196,16 @@ def main():
         f.write("#define LD_BM_POSE_ASM(LX, LY, LZ, L2, A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, X, Y, Z) \\\n  asm( \\\n")
         f.write(" \\\n".join('    "%s\\n\\t"' % l for l in plines) + " \\\n")
         f.write("    : " + ", \\\n      ".join(pouts) + " \\\n    : " + ", \\\n      ".join(pins) + ")\n")
+        flines, fouts, fins = pose_flex_block()
+        f.write("\n// the same for a molecule that flexes: + the two atoms' deformation, then |l|^2 (%d packed instructions)\n" % len(flines))
+        f.write("#define LD_BM_POSE_FLEX_ASM(LX, LY, LZ, L2, A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, X, Y, Z, DX, DY, DZ) \\\n  asm( \\\n")
+        f.write(" \\\n".join('    "%s\\n\\t"' % l for l in flines) + " \\\n")
+        f.write("    : " + ", \\\n      ".join(fouts) + " \\\n    : " + ", \\\n      ".join(fins) + ")\n")
+        xlines, xouts, xins, xclob = flex_block()
+        f.write("\n// a subtile's deformation for the lane's pose: 60 LDS reads, eight in flight, 120 packed multiply-adds (%d instructions)\n" % len(xlines))
+        f.write("#define LD_BM_FLEX_ASM(D, A, MODES) \\\n  asm volatile( \\\n")
+        f.write(" \\\n".join('    "%s\\n\\t"' % l for l in xlines) + " \\\n")
+        f.write("    : " + ", \\\n      ".join(xouts) + " \\\n    : " + ", \\\n      ".join(xins) + " \\\n    : " + ", ".join(xclob) + ")\n")
         dlines, douts, dins = dma_block()
         f.write("\n// a block's 64 table rows -> the wave's cube: 13 ds_bpermute in flight, one wait, 13 LDS-DMA copies\n")
         f.write("#define LD_BM_DMA_ASM(SAVE, TMP, ROWSEL, SRC, PIECE, TABLE, CUBE, M55, M44) \\\n  asm volatile( \\\n")

@@ -41,13 +41,13 @@ def bm_err(got, want):
     return np.max(np.maximum(np.abs(got - want) - BM_ATOL, 0.0) / np.maximum(np.abs(want), 1e-9))
 
 
-RIGID_DFIRE = ("1ppe", "1k4c")   # the fixtures that run the block-major path by default
+BM_DFIRE = ("1ppe", "1k4c", "2uuy", "ab_icode")   # the DFIRE fixtures: the block-major path by default (2uuy, ab_icode: its ANM form)
 
 
 def err_for(name, env=None):
     """The error measure of a fixture's default K1 (or of the kernel `env` forces)."""
     kernel = (env or {}).get("LIGHTDOCK_DFIRE_KERNEL", "bm")
-    return bm_err if name in RIGID_DFIRE and kernel == "bm" else rel_err
+    return bm_err if name in BM_DFIRE and kernel == "bm" else rel_err
 
 
 @pytest.fixture(scope="module")
@@ -425,6 +425,7 @@ def test_real_dcparams_goldens_on_gpu(pkg, orc, real_dcparams):
     {"LIGHTDOCK_PACKED_EPS_SCALE": "8"},      # a wider error band: more pairs on the exact path, same results
     {"LIGHTDOCK_BM_CHUNK": "16"},             # block-major passes of 16 poses, alternating between two streams
     {"LIGHTDOCK_BM_CHUNK": "16", "LIGHTDOCK_BM_LANES": "1"},
+    {"LIGHTDOCK_BM_ANM": "0"},                # molecules that flex stay with the pose-major kernel
     {"LIGHTDOCK_TILED_SPLIT": "2"},
 ])
 @pytest.mark.parametrize("name", ["1ppe", "1k4c", "2uuy"])
@@ -1210,3 +1211,43 @@ def test_block_major_frame_edges_and_absurd_poses(pkg, scorers, orc, name):
     assert bm_err(hip.energy_batch(poses), want_e) < REL_TOL
     assert want_n[:4].min() > 10000 and np.all(want_n[15:21] == 0)
     assert np.array_equal(hip.energy_batch(poses)[23:], hip.energy_batch(base[23:]))     # the neighbours: bit for bit what they are alone
+
+
+@pytest.mark.gpu
+def test_block_major_anm_form_and_wild_amplitudes(pkg, scorers, orc):
+    """DFIRE with normal modes (src/dfire.rs:288-320) runs the block-major path's ANM form: both molecules flex per pose
+    inside the batch.  Its f32 bounds cover deformations up to 32 A; a pose whose amplitudes could exceed that -- or are not
+    finite -- is WILD: every block of it goes to the exact path.  Ordinary, large, absurd, NaN and infinite amplitudes must
+    give the oracle's energies and in-cutoff pair counts, and leave their neighbours bit for bit what they are alone."""
+    torch = pytest.importorskip("torch")
+    hip, cpu = scorers("2uuy")
+    assert hip.kernel_info()["pair_kernel_name"] == "dfire_bm_pairs"
+    base = case_positions("2uuy", orc)[:32].copy()
+    poses = base.copy()
+    assert poses.shape[1] == 27
+    scale = [1, 2, 5, 10, 20, 50, 100, 300, 1e3, 1e5]
+    for i, f in enumerate(scale):
+        poses[i, 7:] *= f
+    poses[10, 7:17] *= 40.0        # the receptor alone flexes wildly
+    poses[11, 17:] *= 40.0         # the ligand alone
+    poses[12, 9] = np.nan
+    poses[13, 20] = np.inf
+    poses[14, 7:] = 0.0            # a rigid pose among them
+    poses[15, 7] = 1e300
+    want = [cpu.energy_ex_row(p) for p in poses]
+    want_e = np.array([w[0] for w in want], dtype=np.float64)
+    want_n = np.array([w[1][5] for w in want]).astype(np.int64)
+    dev = torch.device("cuda:0")
+    d_poses = torch.from_numpy(poses).to(dev)
+    d_out = torch.zeros(len(poses), dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(len(poses), dtype=torch.int32, device=dev)
+    hip.energy_batch_device(len(poses), d_poses.data_ptr(), poses.shape[1], d_out.data_ptr(), None, d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(d_cnt.cpu().numpy().astype(np.int64), want_n)
+    finite = np.isfinite(want_e)
+    assert np.array_equal(np.isnan(got), np.isnan(want_e))
+    assert bm_err(got[finite], want_e[finite]) < REL_TOL
+    again = hip.energy_batch(poses)
+    assert bm_err(again[finite], want_e[finite]) < REL_TOL
+    assert np.array_equal(again[16:], hip.energy_batch(base[16:]))
