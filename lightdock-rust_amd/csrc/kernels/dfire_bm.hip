@@ -154,7 +154,85 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
             // (NaN amplitudes: not below the bound either -> wild -> the exact path, where the reference's arithmetic decides)
             am[20] = reach_rec <= kBmWildUnits && reach_lig <= kBmWildUnits ? 0.f : 1.f;
             am[21] = am[22] = am[23] = 0.f;
+            double *ax = T->amp_exact + listed * (2 * kBmMaxModes);
+#pragma unroll
+            for (int k = 0; k < kBmMaxModes; k++) {
+                ax[k] = k < T->m.anm_rec ? row[7 + k] : 0.0;
+                ax[kBmMaxModes + k] = k < T->m.anm_lig ? row[7 + T->m.anm_rec + k] : 0.0;
+            }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dfire_bm_rec_boxes (ANM): the boxes of the FLEXED receptor, per row of the pass (src/dfire.rs:304-320 moves the receptor's atoms
+// with the pose's amplitudes).  Wave = (receptor tile, 64 rows), LANE = ROW: the lane keeps its row's ten amplitudes, the tile's
+// static records and modes are wave-uniform -- scalar loads, straight into the scalar operands of the packed multiply-adds
+// (two atoms an instruction: 15 per atom pair and coordinate triple... 30 per pair of atoms) --, and the boxes are running
+// minima in the lane's registers: no cross-lane reduction at all.  f32 throughout: the atom of a pose that is not WILD lies
+// within rec_box_pad of the exactly flexed one (scorer.cpp), the boxes are widened by that; a wild row's boxes are not used
+// (the culling kernel lists all of its blocks).
+// (History: first the per-pose boxes came from dfire_packed_prepare -- f64, by pose of the launch whatever the list --, 159 us for
+// 16 384 poses of 2uuy; then from a lane = atom form of this kernel with DPP box reductions, 103 us, bound by its 120 vector
+// instructions per (row, tile).)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dfire_bm_rec_boxes(const BmLaunch launch_arguments) {
+    BmArgs *T = LD_BM_ARGS;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const size_t rows = bm_rows(T);
+    const int n_rt = T->m.rec_n_tiles;
+    const size_t n_items = (rows + 63) / 64 * (size_t)n_rt;
+    const float pad = T->m.rec_box_pad;
+    typedef const __attribute__((address_space(4))) float const_f32;
+    for (size_t item = (size_t)blockIdx.x * 4 + wave; item < n_items; item += (size_t)gridDim.x * 4) {
+        const int RT = (int)(item % (unsigned)n_rt);
+        const size_t row = item / (unsigned)n_rt * 64 + (size_t)lane;
+        const bool have = row < rows;
+        v2f amp[kBmMaxModes / 2];
+        float wild = 1.f;
+        {
+            const float4 *am = reinterpret_cast<const float4 *>(T->amp + (have ? row : 0) * kBmAmpFloats);
+            const float4 q0 = am[0], q1 = am[1], q2 = am[2];
+            amp[0] = v2f{q0.x, q0.y}; amp[1] = v2f{q0.z, q0.w}; amp[2] = v2f{q1.x, q1.y}; amp[3] = v2f{q1.z, q1.w}; amp[4] = v2f{q2.x, q2.y};
+            if (have) wild = reinterpret_cast<const float *>(am)[2 * kBmMaxModes];
+        }
+        float tlo[3] = {INFINITY, INFINITY, INFINITY}, thi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll 1
+        for (int sb = 0; sb < 8; sb++) {
+            const_f32 *modes = (const_f32 *)(uintptr_t)(T->m.rec_modes_f32 + ((size_t)RT * 8 + (size_t)sb) * kBmModeFloats);
+            const_f32 *recs = (const_f32 *)(uintptr_t)(T->m.rec_pairs + (size_t)RT * 32 + (size_t)sb * 4);   // 4 records: x0 x1 y0 y1 z0 z1 . .
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int first = RT * 64 + sb * 8 + 2 * q;   // (padding atoms -- the tail of the last tile -- are in no box)
+                if (first >= T->m.rec_n_real) break;
+                const bool both = first + 1 < T->m.rec_n_real;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    v2f f{recs[q * 8 + 2 * c], recs[q * 8 + 2 * c + 1]};
+#pragma unroll
+                    for (int k2 = 0; k2 < kBmMaxModes / 2; k2++) {
+                        const_f32 *m = modes + ((q * 3 + c) * kBmMaxModes + 2 * k2) * 2;
+                        f = __builtin_elementwise_fma(v2f{amp[k2].x, amp[k2].x}, v2f{m[0], m[1]}, f);
+                        f = __builtin_elementwise_fma(v2f{amp[k2].y, amp[k2].y}, v2f{m[2], m[3]}, f);
+                    }
+                    const float second = both ? f.y : f.x;
+                    lo[c] = fminf(lo[c], fminf(f.x, second));
+                    hi[c] = fmaxf(hi[c], fmaxf(f.x, second));
+                }
+            }
+            if (have && wild == 0.f)
+                reinterpret_cast<BmCullBox *>(T->anm_sub)[(row * (size_t)n_rt + RT) * 8 + sb] =
+                    BmCullBox{v2f{lo[0] - pad, -(hi[0] + pad)}, v2f{lo[1] - pad, -(hi[1] + pad)}, v2f{lo[2] - pad, -(hi[2] + pad)}, v2f{0.f, 0.f}};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                tlo[c] = fminf(tlo[c], lo[c]);
+                thi[c] = fmaxf(thi[c], hi[c]);
+            }
+        }
+        if (have && wild == 0.f)
+            T->anm_tile[row * (size_t)n_rt + RT] = TiledBox{tlo[0] - pad, tlo[1] - pad, tlo[2] - pad, 0.f, thi[0] + pad, thi[1] + pad, thi[2] + pad, 0.f};
     }
 }
 
@@ -164,8 +242,8 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
 // tile: ONE atomic per tile pair for all the poses of the wave (the lists of a small complex have few heads: one
 // returning atomic per pose and tile pair serialises on them), then the entries.
 // ---------------------------------------------------------------------------------------------
-// ANM (DFIRE with normal modes, src/dfire.rs:288-320): the receptor's boxes differ per pose -- read from the per-pose images
-// dfire_packed_prepare wrote (BmLaunch::anm_sub / anm_tile) instead of the static ones in LDS -- and the ligand tile's atoms are
+// ANM (DFIRE with normal modes, src/dfire.rs:288-320): the receptor's boxes differ per pose -- read from what dfire_bm_rec_boxes
+// wrote for the row (BmLaunch::anm_sub / anm_tile) instead of the static ones in LDS -- and the ligand tile's atoms are
 // flexed after the affine map: + sum_k amplitude_k x mode_k of the atom (kappa x, f32; the amplitudes from the [row] table).
 template <bool COUNT, bool ANM>
 __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunch launch_arguments) {
@@ -356,22 +434,18 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         }
         // ANM: this pose's receptor boxes (global memory, the pose's image) and how far its amplitudes can move a ligand atom
         const TiledBox *tiles_g = nullptr;
-        const TiledBox *subs_g = nullptr;
+        const BmCullBox *subs_g = nullptr;
         float flex_reach = 0.f;
         if (ANM) {
-            tiles_g = T->anm_tile + (size_t)pose_of[g] * n_rt;
-            subs_g = T->anm_sub + (size_t)pose_of[g] * n_rt * 8;
+            tiles_g = T->anm_tile + (listed0 + (size_t)g) * n_rt;
+            subs_g = reinterpret_cast<const BmCullBox *>(T->anm_sub) + (listed0 + (size_t)g) * n_rt * 8;
             my_tile = lane < n_rt ? tiles_g[lane] : no_tile;
 #pragma unroll
             for (int k = 0; k < kBmMaxModes; k++) flex_reach = __builtin_fmaf(fabsf(pose_lane(my_amp[k], g)), T->m.lig_mode_reach[k], flex_reach);
             flex_reach *= 1.0001f;
         }
         auto tile_at = [&](int i) { return ANM ? tiles_g[i] : s_tile[i]; };
-        auto sub_at = [&](int i) {   // subtile i of the receptor as {lo, -hi} pairs
-            if (!ANM) return s_sub[i];
-            const TiledBox t = subs_g[i];
-            return BmCullBox{v2f{t.lox, -t.hix}, v2f{t.loy, -t.hiy}, v2f{t.loz, -t.hiz}, v2f{0.f, 0.f}};
-        };
+        auto sub_at = [&](int i) { return ANM ? subs_g[i] : s_sub[i]; };   // subtile i of the receptor as {lo, -hi} pairs
         {   // A tile whose bounding sphere stays beyond the cutoff of every receptor tile's box has nothing to list (most tiles
             // of a large ligand, in most poses): one point posed and one test per receptor tile instead of 64 atoms posed,
             // their boxes and the box tests.
@@ -748,21 +822,23 @@ __device__ __forceinline__ void bm_exact_pairs(BmArgs *T, unsigned long long *qu
             double px = r.x + pr[u][0], py = r.y + pr[u][1], pz = r.z + pr[u][2];
             double rx = rc[u][0], ry = rc[u][1], rz = rc[u][2];
             if (T->amp != nullptr) {   // molecules that flex: src/dfire.rs:288-320, the operations of pose_ligand_atom and exact_pair (dfire_device.hpp)
-                const double *prow = T->poses + pose[u] * T->stride;
-                const size_t lpad = (size_t)T->m.lig.n_tiles * 64, rpad = T->m.rec_pad;
-                for (int k = 0; k < T->m.anm_lig; k++) {
-                    const double c = prow[7 + T->m.anm_rec + k];
-                    const double *m = T->m.lig.modes + (size_t)k * 3 * lpad;
-                    px += m[la[u]] * c;
-                    py += m[lpad + la[u]] * c;
-                    pz += m[2 * lpad + la[u]] * c;
-                }
-                for (int k = 0; k < T->m.anm_rec; k++) {
-                    const double c = prow[7 + k];
-                    const double *m = T->m.rec_modes + (size_t)k * 3 * rpad;
-                    rx += m[ra[u]] * c;
-                    ry += m[rpad + ra[u]] * c;
-                    rz += m[2 * rpad + ra[u]] * c;
+                // (an atom's modes and a row's amplitudes in 16-byte pieces of contiguous memory: mode by mode out of the [mode][xyz][atom]
+                // arrays a pair was 60 scattered 8-byte loads, and the ANM form's waves spent a fifth of their time here)
+                const v2d *amps = reinterpret_cast<const v2d *>(T->amp_exact + row[u] * (2 * kBmMaxModes));
+                const v2d *lm = reinterpret_cast<const v2d *>(T->m.lig_modes_exact + (size_t)la[u] * (3 * kBmMaxModes));
+                const v2d *rm = reinterpret_cast<const v2d *>(T->m.rec_modes_exact + (size_t)ra[u] * (3 * kBmMaxModes));
+#pragma unroll
+                for (int k2 = 0; k2 < kBmMaxModes / 2; k2++) {   // modes 2 k2 and 2 k2 + 1: x y z x y z
+                    if (2 * k2 < T->m.anm_lig) {
+                        const v2d c = amps[kBmMaxModes / 2 + k2], m0 = lm[3 * k2], m1 = lm[3 * k2 + 1], m2 = lm[3 * k2 + 2];
+                        px += m0.x * c.x; py += m0.y * c.x; pz += m1.x * c.x;
+                        if (2 * k2 + 1 < T->m.anm_lig) { px += m1.y * c.y; py += m2.x * c.y; pz += m2.y * c.y; }
+                    }
+                    if (2 * k2 < T->m.anm_rec) {
+                        const v2d c = amps[k2], m0 = rm[3 * k2], m1 = rm[3 * k2 + 1], m2 = rm[3 * k2 + 2];
+                        rx += m0.x * c.x; ry += m0.y * c.x; rz += m1.x * c.x;
+                        if (2 * k2 + 1 < T->m.anm_rec) { rx += m1.y * c.y; ry += m2.x * c.y; rz += m2.y * c.y; }
+                    }
                 }
             }
             const double dx = 2.0 * rx - 2.0 * px, dy = 2.0 * ry - 2.0 * py, dz = 2.0 * rz - 2.0 * pz;
@@ -1489,6 +1565,8 @@ hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     if (anm) {
+        const size_t items = (t.n_poses + 63) / 64 * (size_t)t.m.rec_n_tiles;
+        hipLaunchKernelGGL(dfire_bm_rec_boxes, dim3((unsigned)std::min<size_t>((items + 3) / 4, cus * 8)), dim3(256), 0, stream, t);
         if (count) hipLaunchKernelGGL((dfire_bm_cull<true, true>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
         else hipLaunchKernelGGL((dfire_bm_cull<false, true>), dim3((unsigned)blocks), dim3(kBmCullWaves * 64), lds, stream, t);
     } else {

@@ -139,8 +139,10 @@ struct BmModel {
     const float *rec_modes_f32 = nullptr;       // [rec subtiles][kBmModeFloats]: kappa x the modes, f32, in the batch's order (absent modes 0)
     const float *lig_modes_f32 = nullptr;       // [lig subtiles][kBmModeFloats]
     const float *lig_modes_atom = nullptr;      // [lig atoms (tile order)][32]: the same modes per atom, [mode][x y z] (the culling kernel: lane = atom)
-    const double *rec_modes = nullptr;          // f64 [mode][xyz][rec_pad]: the exact path (src/dfire.rs:304-320)
-    size_t rec_pad = 0;
+    const float *rec_modes_atom = nullptr;      // [rec atoms (tile order)][32]: the same for the receptor (dfire_bm_rec_boxes)
+    float rec_box_pad = 0.f;                    // record units: how far an f32-flexed receptor atom of a pose that is not wild can be from the exact one, per coordinate
+    const double *rec_modes_exact = nullptr;    // f64 [atom (tile order)][kBmMaxModes][x y z]: what the exact path reads of an atom's modes, 240 contiguous bytes
+    const double *lig_modes_exact = nullptr;    //   (src/dfire.rs:288-320; absent modes 0, never read)
     float rec_mode_reach[kBmMaxModes] = {}, lig_mode_reach[kBmMaxModes] = {};   // kappa x the largest |mode vector| of an atom, per mode: sum |amplitude| x this bounds a pose's deformation
     // ligand
     TiledLigand lig;                            // f64, tile order (exact path, overflow tiles)
@@ -178,8 +180,9 @@ struct BmLaunch {
     int count_mode = 0;                    // 1: a counting launch -- full LUT, rows of ones, the sums are in-cutoff pair counts (-> count_partial)
     // workspace of the pass; "row" = row of the pass
     float *amp = nullptr;                  // ANM: [row][kBmAmpFloats] f32 amplitudes (dfire_bm_pose), or nullptr
-    const TiledBox *anm_sub = nullptr;     // ANM: the receptor's subtile boxes per POSE [pose][n_rt * 8] (dfire_packed_prepare, the kappa = 8 frame) ...
-    const TiledBox *anm_tile = nullptr;    // ... and tile boxes [pose][n_rt]
+    double *amp_exact = nullptr;           // ANM: [row][2 * kBmMaxModes] the pose's own f64 amplitudes, receptor's then ligand's (the exact path: 16-byte loads)
+    TiledBox *anm_sub = nullptr;           // ANM: the flexed receptor's subtile boxes per ROW [row][n_rt * 8], as {lo, -hi} pairs (dfire_bm_rec_boxes) ...
+    TiledBox *anm_tile = nullptr;          // ... and tile boxes [row][n_rt]
     uint32_t part_cap = 0;                 // entries per part at most (kBmPartEntries, or kBmAnmPartEntries for the ANM form)
     float *rt = nullptr;                   // [row][12]: the pose as an f32 affine map
     double *rt_exact = nullptr;            // [row][8]: the pose as the exact path reads it: t, q (f64, the launch's own numbers), its index in the launch

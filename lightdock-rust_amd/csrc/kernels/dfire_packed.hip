@@ -80,14 +80,12 @@ __global__ __launch_bounds__(64) void dfire_packed_prepare(const PackedPrepareLa
     const float fx = frame_coord(x, P.cx, P.kappa), fy = frame_coord(y, P.cy, P.kappa), fz = frame_coord(z, P.cz, P.kappa);
     const bool inside = fabsf(fx) <= P.ubound && fabsf(fy) <= P.ubound && fabsf(fz) <= P.ubound;
     // record (4 j + q) of the tile holds the atoms (2 q, 2 q + 1) of its subtile j
-    if (P.pairs_out != nullptr) {   // (null: the boxes only -- the block-major path's culling kernel for molecules that flex)
-        float *rec = reinterpret_cast<float *>(P.pairs_out + (pose * (size_t)P.n_tiles + tile) * 32 + (lane >> 1));
-        const int h = lane & 1;
-        rec[h] = real ? fx : -1.0e30f;
-        rec[2 + h] = real ? fy : 0.f;
-        rec[4 + h] = real ? fz : 0.f;
-        reinterpret_cast<uint32_t *>(rec)[6 + h] = my_term | (real && !inside ? kPackedSlow : 0u);
-    }
+    float *rec = reinterpret_cast<float *>(P.pairs_out + (pose * (size_t)P.n_tiles + tile) * 32 + (lane >> 1));
+    const int h = lane & 1;
+    rec[h] = real ? fx : -1.0e30f;
+    rec[2 + h] = real ? fy : 0.f;
+    rec[4 + h] = real ? fz : 0.f;
+    reinterpret_cast<uint32_t *>(rec)[6 + h] = my_term | (real && !inside ? kPackedSlow : 0u);
     BoxRegs b = lane_box(real, fx, fy, fz);
     box_reduce8(b);
     {

@@ -927,10 +927,13 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     if (anm) {   // the modes as the kernels read them: kappa x, f32 (BmModel)
         M.anm_rec = rec.num_anm;
         M.anm_lig = lig.num_anm;
-        M.rec_modes = rec.modes;
-        M.rec_pad = (size_t)rec.n_tiles * 64;
-        auto tables = [&](const TiledSoA &m, std::vector<float> &by_subtile, std::vector<float> *by_atom, float *reach) {
+        auto tables = [&](const TiledSoA &m, std::vector<float> &by_subtile, std::vector<float> *by_atom, float *reach, const double **exact) {
             const size_t pad = (size_t)m.n_tiles * 64;
+            std::vector<double> per_atom(pad * 3 * (size_t)kBmMaxModes, 0.0);   // [atom][mode][x y z], the reference's numbers
+            for (int k = 0; k < m.num_anm; k++)
+                for (size_t i = 0; i < pad; i++)
+                    for (int c = 0; c < 3; c++) per_atom[(i * kBmMaxModes + (size_t)k) * 3 + c] = m.hmodes[((size_t)k * 3 + c) * pad + i];
+            *exact = arena_.upload(per_atom);
             by_subtile.assign(pad / 8 * (size_t)kBmModeFloats, 0.f);
             if (by_atom) by_atom->assign(pad * 32, 0.f);
             for (int k = 0; k < kBmMaxModes; k++) reach[k] = 0.f;
@@ -951,12 +954,15 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
                 reach[k] = std::nextafter((float)(kBmKappa * longest * 1.001), INFINITY);
             }
         };
-        std::vector<float> rsub, lsub, latom;
-        tables(rec, rsub, nullptr, M.rec_mode_reach);
-        tables(lig, lsub, &latom, M.lig_mode_reach);
+        std::vector<float> rsub, lsub, latom, ratom;
+        tables(rec, rsub, &ratom, M.rec_mode_reach, &M.rec_modes_exact);
+        tables(lig, lsub, &latom, M.lig_mode_reach, &M.lig_modes_exact);
         M.rec_modes_f32 = arena_.upload(rsub);
         M.lig_modes_f32 = arena_.upload(lsub);
         M.lig_modes_atom = arena_.upload(latom);
+        M.rec_modes_atom = arena_.upload(ratom);
+        // dfire_bm_rec_boxes' atoms: the static record's rounding, the ten terms and their fma roundings (partial sums inside the frame); x 2
+        M.rec_box_pad = std::nextafter((float)(2.0 * (std::ldexp(ubound, -24) + bm_flex_error(ubound * 0.999))), INFINITY);
     }
     const uint32_t kPad = std::numeric_limits<uint32_t>::max();
     {   // per atom: where its type's rows / column sit in the row table; padding atoms take the all-zero type
@@ -1101,21 +1107,7 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         t.exact_partial = static_cast<uint32_t *>(ws_exact_.ptr);
     }
     const bool anm = bm_.anm_rec + bm_.anm_lig > 0;
-    if (anm) {   // every pose's receptor boxes in the block-major frame (src/dfire.rs:304-320 moves the receptor's atoms per pose)
-        PackedPrepareLaunch pr = packed_prepare_launch(d_poses, stride, d_active, n);
-        pr.cx = bm_.cx;
-        pr.cy = bm_.cy;
-        pr.cz = bm_.cz;
-        pr.kappa = kBmKappa;
-        pr.ubound = bm_.ubound;
-        pr.pairs_out = nullptr;   // (the boxes only)
-        pr.sub_out = static_cast<TiledBox *>(ws_rec_sub_.ptr);
-        pr.tile_out = static_cast<TiledBox *>(ws_rec_tile_.ptr);
-        hip_check(launch_packed_prepare(pr, stream_), "launch dfire_packed_prepare");
-        t.anm_sub = pr.sub_out;
-        t.anm_tile = pr.tile_out;
-        t.part_cap = (uint32_t)kBmAnmPartEntries;
-    }
+    if (anm) t.part_cap = (uint32_t)kBmAnmPartEntries;
     const char *dbg = std::getenv("LIGHTDOCK_BM_DEBUG");
     if (dbg) {
         ws_bm_debug_.reserve(waves * 8 * sizeof(unsigned long long));
@@ -1150,6 +1142,10 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
         t.tile_sum = static_cast<long long *>(ws_bm_tile_sum_.ptr) + w * cap * n_lt;
         t.exact_fix = static_cast<long long *>(ws_bm_exact_fix_.ptr) + w * cap;
         t.amp = anm ? static_cast<float *>(ws_bm_amp_.ptr) + w * cap * kBmAmpFloats : nullptr;
+        // the flexed receptor's boxes of the pass's rows: subtile boxes of every set, then the tile boxes
+        t.anm_sub = anm ? static_cast<TiledBox *>(ws_rec_sub_.ptr) + w * cap * (size_t)bm_.rec_n_tiles * 8 : nullptr;
+        t.anm_tile = anm ? static_cast<TiledBox *>(ws_rec_tile_.ptr) + w * cap * (size_t)bm_.rec_n_tiles : nullptr;
+        t.amp_exact = anm ? reinterpret_cast<double *>(static_cast<float *>(ws_bm_amp_.ptr) + bm_sets(n) * cap * kBmAmpFloats) + w * cap * 2 * kBmMaxModes : nullptr;
         // With pair counts wanted the sequence runs twice: first as a counting launch (the same kernels over rows of ones and the
         // full LUT: the sums are the in-cutoff pair counts), then for the energies.
         for (int mode = counts ? 1 : 0; mode >= 0; mode--) {
@@ -1286,9 +1282,9 @@ void Scorer::reserve_workspace(size_t n_poses, bool counts) {
         ws_bm_tile_sum_.reserve(sets * cap * n_lt * sizeof(long long));
         ws_bm_exact_fix_.reserve(sets * cap * sizeof(long long));
         if (bm_.anm_rec + bm_.anm_lig > 0) {   // the poses' amplitudes by row, and the receptor's boxes by pose
-            ws_bm_amp_.reserve(sets * cap * kBmAmpFloats * sizeof(float));
-            ws_rec_sub_.reserve(n_poses * n_rt * 8 * sizeof(TiledBox));
-            ws_rec_tile_.reserve(n_poses * n_rt * sizeof(TiledBox));
+            ws_bm_amp_.reserve(sets * cap * (kBmAmpFloats * sizeof(float) + 2 * kBmMaxModes * sizeof(double)));   // every set's f32 rows, then the f64 ones
+            ws_rec_sub_.reserve(sets * cap * n_rt * 8 * sizeof(TiledBox));
+            ws_rec_tile_.reserve(sets * cap * n_rt * sizeof(TiledBox));
         }
         if (counts) {
             ws_bm_tile_tested_.reserve(sets * cap * n_lt * sizeof(uint32_t));
