@@ -1009,11 +1009,19 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
     unsigned long long dbg_jobs = 0, dbg_batches = 0, dbg_t_batch = 0, dbg_t_drain = 0, dbg_t_scan = 0, dbg_t_block = 0;
     auto now = [] { return DEBUG ? __builtin_amdgcn_s_memrealtime() : 0ull; };
 
+    // A wave's FIRST job is its own number in the launch -- no draw: the 2048 waves of a launch all start at once, and their 2048
+    // returning atomics on one counter (device scope: resolved behind the XCDs' L2s) queued for ~20 us before the first job's
+    // set-up could begin, in every launch; a GSO step with few glowworms moving is one job per wave and little else.
+    const uint32_t n_waves = gridDim.x * (uint32_t)kBmWaves;
+    bool first_job = true;
     for (;;) {
         const unsigned long long dbg_tj = now();
-        uint32_t job = 0;
-        if (lane == 0) job = atomicAdd(T->job_next, 1u);   // (drawing one job ahead was measured: the 2048 claimed jobs lengthen the tail)
-        job = (uint32_t)__builtin_amdgcn_readfirstlane((int)job);
+        uint32_t job = blockIdx.x * (uint32_t)kBmWaves + (uint32_t)wave;
+        if (!first_job) {
+            if (lane == 0) job = atomicAdd(T->job_next, 1u);   // (drawing one job ahead was measured: the 2048 claimed jobs lengthen the tail)
+            job = (uint32_t)__builtin_amdgcn_readfirstlane((int)job) + n_waves;
+        }
+        first_job = false;
         if (job >= n_jobs) break;
         job = T->job_order[job];   // longest first (dfire_bm_order)
         // (the job's record as dfire_bm_census wrote it: one load; its pieces one by one -- the (tile pair, part) pair, then the tile
