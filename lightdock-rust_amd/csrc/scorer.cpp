@@ -1108,6 +1108,10 @@ void Scorer::run_bm(size_t n, const double *d_poses, size_t stride, const uint8_
     }
     const bool anm = bm_.anm_rec + bm_.anm_lig > 0;
     if (anm) t.part_cap = (uint32_t)kBmAnmPartEntries;
+    if (const char *e = std::getenv("LIGHTDOCK_BM_PART_CAP")) {   // A/B: jobs of fewer entries than the LDS has room for (a multiple of 64)
+        const long v = std::atol(e);
+        if (v >= 64 && v % 64 == 0 && (uint32_t)v <= (anm ? (uint32_t)kBmAnmPartEntries : (uint32_t)kBmPartEntries)) t.part_cap = (uint32_t)v;
+    }
     const char *dbg = std::getenv("LIGHTDOCK_BM_DEBUG");
     if (dbg) {
         ws_bm_debug_.reserve(waves * 8 * sizeof(unsigned long long));
