@@ -709,8 +709,11 @@ struct BmWaveSharedT {
     static constexpr int kPart = ANM ? kBmAnmPartEntries : kBmPartEntries;
     unsigned char row_bits[kPart];        // per entry of the job: which of the 8 blocks (a, .) it holds
     unsigned short items[kPart];          // the entries that hold the current block
-    unsigned short rows[kPart];           // per entry of the job: its row of the pass (where its affine map is), bits 0..15
-    unsigned char rows_hi[kPart / 4];     // ... and bits 16, 17: four entries to a byte (a pass holds up to 2^18 rows)
+    // per entry of the job: its row of the pass (where its affine map is), bits 0..15, and bits 16, 17 four entries to a byte (a
+    // pass holds up to 2^18 rows).  The ANM form has no room for them next to its modes: it reads an item's row from the entry
+    // list in global memory, two batches ahead like the rigid form's LDS read.
+    unsigned short rows[ANM ? 2 : kPart];
+    unsigned char rows_hi[ANM ? 4 : kPart / 4];
     alignas(16) float modes[ANM ? 2 * kBmModeFloats : 4];   // ANM: [ligand subtile][receptor subtile] x kBmModeFloats
 };
 template <bool ANM>
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 m[k] = mask_at[k * 64];
-                r[k] = row_at[k * 64];
+                r[k] = ANM ? 0u : row_at[k * 64];   // (the ANM form: per item, from the list itself)
             }
             const uint32_t n_mine = hi - lo;   // entries of the part
 #pragma unroll
@@ -1059,11 +1062,11 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 const uint32_t bits = (uint32_t)(k * 64 + lane) < n_mine ? (uint32_t)(m[k] >> (8 * a)) & 0xffu : 0u;
                 if (k < n_chunks) {
                     WS.row_bits[k * 64 + lane] = (unsigned char)bits;
-                    WS.rows[k * 64 + lane] = (unsigned short)r[k];
+                    if constexpr (!ANM) WS.rows[k * 64 + lane] = (unsigned short)r[k];
                 }
                 any_bits |= bits;
             }
-            if (__builtin_expect(wide_rows, 0)) {   // the rows' bits 16 and 17, four lanes to a byte (a pass of more than 2^16 rows: a GSO over hundreds of swarms)
+            if (!ANM && __builtin_expect(wide_rows, 0)) {   // the rows' bits 16 and 17, four lanes to a byte (a pass of more than 2^16 rows: a GSO over hundreds of swarms)
 #pragma unroll 1
                 for (int k = 0; k < n_chunks; k++) {
                     uint32_t rk = r[0];
@@ -1116,6 +1119,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         // scattered read-modify-writes of HBM per launch)
         long long *const my_partial = T->ent_partial + ((size_t)blockIdx.x * kBmWaves + wave) * kBmPartEntries;
         const size_t row_base_entry = tp * T->cap + lo;
+        const uint32_t *const job_rows = T->ent_row + row_base_entry;   // (ANM form: an item's row of the pass)
         const uint32_t dma_rowsel = (uint32_t)(lane / kRowPieces) * 4u, dma_piece = (uint32_t)(lane % kRowPieces) * 16u;   // (constants of the lane: row of the five, piece)
         if (DEBUG) dbg_t_scan += now() - dbg_tj;   // job set-up
         // a batch's results, on their way out one batch late (see run_batch)
@@ -1209,20 +1213,28 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
             };
             // the entry's row of the pass, and in bits 30 / 31 of the same word whether block b is the entry's LAST / FIRST of this job
             // (last: the (entry, row)'s sum is complete; first: nothing to add to yet) -- from the entry's byte of block bits
+            struct RowOfItem {
+                uint32_t row;     // the entry's row of the pass (ANM form: as loaded from the entry list -- nothing may be computed from it before the loop's wait)
+                uint32_t flags;   // bit 31: block b is the entry's FIRST of this job, bit 30: its LAST
+            };
             auto read_row = [&](uint32_t item) {
                 const uint32_t el = item & 0x3ffu;
-                uint32_t row = (uint32_t)WS.rows[el];
+                RowOfItem r;
                 const uint32_t bits = (uint32_t)WS.row_bits[el];
-                if (wide_rows) row |= (((uint32_t)WS.rows_hi[el >> 2] >> (2 * (el & 3))) & 3u) << 16;
+                if constexpr (ANM) {
+                    r.row = job_rows[el];
+                } else {
+                    r.row = (uint32_t)WS.rows[el];
+                    if (wide_rows) r.row |= (((uint32_t)WS.rows_hi[el >> 2] >> (2 * (el & 3))) & 3u) << 16;
+                }
                 // (x - 1) has bit 31 set exactly when x = 0, for x below 2^31
-                row |= ((bits & ((1u << b) - 1u)) - 1u) & 0x80000000u;
-                row |= (((bits >> (b + 1)) - 1u) >> 1) & 0x40000000u;
-                return row;
+                r.flags = (((bits & ((1u << b) - 1u)) - 1u) & 0x80000000u) | ((((bits >> (b + 1)) - 1u) >> 1) & 0x40000000u);
+                return r;
             };
-            auto issue_loads = [&](uint32_t item_el, uint32_t row_and_flags) {
+            auto issue_loads = [&](uint32_t item_el, const RowOfItem &of) {
                 BatchLoads L;
-                const uint32_t item = (item_el & 0x3ffu) | (row_and_flags >> 16 & 0xc000u);   // entry | first << 15 | last << 14, as the code below reads it
-                const uint32_t row = row_and_flags & 0x3ffffu;
+                const uint32_t item = (item_el & 0x3ffu) | (of.flags >> 16 & 0xc000u);   // entry | first << 15 | last << 14, as the code below reads it
+                const uint32_t row = of.row & 0x3ffffu;
                 L.item = item;
                 L.row = row;
 #ifndef LD_BM_DIAG_ROW_OF_LANE
@@ -1245,7 +1257,8 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 return L;
             };
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the item list as every lane wrote it
-            uint32_t look_item, look_row, look2_item;   // batch 1's item and row, batch 2's item
+            uint32_t look_item, look2_item;   // batch 1's item, batch 2's item
+            RowOfItem look_row;               // batch 1's row
             BatchLoads next;
             {
                 const uint32_t item0 = read_item(0u);
@@ -1429,7 +1442,8 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 // a write or two, waited for the first of the loads just issued: a round trip to the L2 in every batch.)
                 asm volatile("" :: "v"(next.a0.x), "v"(next.a0.y), "v"(next.a0.z), "v"(next.a0.w), "v"(next.a1.x), "v"(next.a1.y), "v"(next.a1.z), "v"(next.a1.w),
                              "v"(next.a2.x), "v"(next.a2.y), "v"(next.a2.z), "v"(next.a2.w), "v"(next.prev));
-                if constexpr (ANM) asm volatile("" :: "v"(next.amp[0].x), "v"(next.amp[1].x), "v"(next.amp[2].x), "v"(next.amp[3].x), "v"(next.amp[4].x), "v"(next.amp[5].x));
+                // (ANM: also the row of the batch after this one, a load from the entry list: its wait belongs here too, not behind the stores below)
+                if constexpr (ANM) asm volatile("" :: "v"(next.amp[0].x), "v"(next.amp[1].x), "v"(next.amp[2].x), "v"(next.amp[3].x), "v"(next.amp[4].x), "v"(next.amp[5].x), "v"(look_row.row));
                 const BatchLoads cur = next;
 #ifdef LD_BM_DIAG_WAIT   // (diagnostic builds: the drain timer holds the time a wave waits at the head of its batches for their loads)
                 if (DEBUG) dbg_t_drain += now() - dbg_tb;
@@ -1449,7 +1463,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 // loads land in the registers the next trip reads them from: behind a branch the compiler moved them there
                 // right away, i.e. waited for them)
                 next = issue_loads(look_item, look_row);
-                const uint32_t in_row = read_row(look2_item);                   // batch k + 2's row
+                const RowOfItem in_row = read_row(look2_item);                  // batch k + 2's row
                 const uint32_t in_item = read_item(first_of(done + 192u));      // batch k + 3's item
                 switch (wave) {
                     case 0: run_batch(std::integral_constant<int, 0>{}, cur, done); break;

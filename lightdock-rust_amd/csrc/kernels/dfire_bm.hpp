@@ -74,7 +74,7 @@ constexpr int kBmOpsFloats = 36;             // BmModel::rec_ops: Rs[4][2], Rz[4
 constexpr int kBmMaxModes = 10;              // normal modes per molecule the ANM form of the path takes (the reference's examples: 10 + 10, src/dfire.rs:288-320)
 constexpr int kBmModeFloats = 8 * 3 * kBmMaxModes;   // a subtile's modes as a batch reads them: ((atom pair p * 3 + coordinate) * kBmMaxModes + mode) * 2 + atom of the pair
 constexpr int kBmAmpFloats = 24;             // a row's amplitudes as the pair kernel loads them: receptor modes 0..9, ligand modes 10..19, [20] != 0: a WILD pose
-constexpr int kBmAnmPartEntries = 512;       // entries of a tile pair in one job of the ANM form (its LDS holds two subtiles' modes where the other keeps 512 entries more)
+constexpr int kBmAnmPartEntries = 1024;      // entries of a tile pair in one job of the ANM form (its LDS holds two subtiles' modes where the other keeps the entries' rows of the pass)
 constexpr float kBmWildUnits = 256.0f;       // a pose whose amplitudes could move an atom further than this (record units: 32 A) is WILD: every pair of its
                                              // blocks goes to the exact path (the f32 arithmetic's error bound covers deformations up to here)
 constexpr int kBmCubeRows = 64;              // table rows of a block: 8 ligand x 8 receptor atoms

@@ -426,6 +426,7 @@ def test_real_dcparams_goldens_on_gpu(pkg, orc, real_dcparams):
     {"LIGHTDOCK_BM_CHUNK": "16"},             # block-major passes of 16 poses, alternating between two streams
     {"LIGHTDOCK_BM_CHUNK": "16", "LIGHTDOCK_BM_LANES": "1"},
     {"LIGHTDOCK_BM_ANM": "0"},                # molecules that flex stay with the pose-major kernel
+    {"LIGHTDOCK_BM_PART_CAP": "64"},          # jobs of 64 entries: every block a single batch, every entry's sum through many jobs
     {"LIGHTDOCK_TILED_SPLIT": "2"},
 ])
 @pytest.mark.parametrize("name", ["1ppe", "1k4c", "2uuy"])
@@ -1251,3 +1252,32 @@ def test_block_major_anm_form_and_wild_amplitudes(pkg, scorers, orc):
     again = hip.energy_batch(poses)
     assert bm_err(again[finite], want_e[finite]) < REL_TOL
     assert np.array_equal(again[16:], hip.energy_batch(base[16:]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rec_modes,n_lig_modes", [(10, 0), (0, 10), (3, 7), (1, 1)])
+def test_block_major_anm_with_one_rigid_molecule_or_fewer_modes(pkg, orc, table, n_rec_modes, n_lig_modes):
+    """The ANM form keeps room for ten modes a molecule; fewer (or none on one side: src/dfire.rs:288-320 loops over what the
+    model holds) leave amplitudes and modes zero there.  Energies and in-cutoff pair counts against the oracle built the same way."""
+    torch = pytest.importorskip("torch")
+    method, rec, lig, kw = case_kwargs("2uuy", orc, table)
+    full_rec, full_lig = np.asarray(kw["rec_nmodes"], dtype=np.float64).ravel(), np.asarray(kw["lig_nmodes"], dtype=np.float64).ravel()
+    kw = dict(kw, rec_num_anm=n_rec_modes, lig_num_anm=n_lig_modes,
+              rec_nmodes=full_rec[: full_rec.size // 10 * n_rec_modes] if n_rec_modes else None,
+              lig_nmodes=full_lig[: full_lig.size // 10 * n_lig_modes] if n_lig_modes else None)
+    hip = pkg.Scorer.from_pdb(method, rec, lig, **kw)
+    cpu = orc.Scorer(method, rec, lig, **kw)
+    assert hip.kernel_info()["pair_kernel_name"] == "dfire_bm_pairs"
+    base = case_positions("2uuy", orc)[:48]
+    poses = np.ascontiguousarray(np.concatenate([base[:, :7], base[:, 7:7 + n_rec_modes], base[:, 17:17 + n_lig_modes]], axis=1))
+    want = [cpu.energy_ex_row(p) for p in poses]
+    want_e = np.array([w[0] for w in want], dtype=np.float64)
+    want_n = np.array([w[1][5] for w in want]).astype(np.int64)
+    dev = torch.device("cuda:0")
+    d_poses = torch.from_numpy(poses).to(dev)
+    d_out = torch.zeros(len(poses), dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(len(poses), dtype=torch.int32, device=dev)
+    hip.energy_batch_device(len(poses), d_poses.data_ptr(), poses.shape[1], d_out.data_ptr(), None, d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_cnt.cpu().numpy().astype(np.int64), want_n)
+    assert bm_err(d_out.cpu().numpy(), want_e) < REL_TOL
