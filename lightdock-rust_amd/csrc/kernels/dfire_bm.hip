@@ -612,9 +612,10 @@ __global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_census(const BmLa
         const uint32_t lo = T->jobs[2 * jd + 1];
         const uint32_t n = T->tp_count[tp];
         const uint32_t size = bm_part_size(n, P), hi = n < lo + size ? n : lo + size;
-        unsigned long long m[16];
+        constexpr int kChunks = kBmPartEntries / 64;
+        unsigned long long m[kChunks];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
+        for (int k = 0; k < kChunks; k++) {
             const uint32_t e = lo + (uint32_t)k * 64 + lane;
             m[k] = e < hi ? T->ent_mask[tp * T->cap + e] : 0ull;
         }
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(kBmOrderWaves * 64) void dfire_bm_census(const BmLa
 #pragma unroll
         for (int r = 0; r < 8; r++) items[r] = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
+        for (int k = 0; k < kChunks; k++) {
             present_lo |= (uint32_t)m[k];
             present_hi |= (uint32_t)(m[k] >> 32);
 #pragma unroll
@@ -709,11 +710,9 @@ struct BmWaveSharedT {
     static constexpr int kPart = ANM ? kBmAnmPartEntries : kBmPartEntries;
     unsigned char row_bits[kPart];        // per entry of the job: which of the 8 blocks (a, .) it holds
     unsigned short items[kPart];          // the entries that hold the current block
-    // per entry of the job: its row of the pass (where its affine map is), bits 0..15, and bits 16, 17 four entries to a byte (a
-    // pass holds up to 2^18 rows).  The ANM form has no room for them next to its modes: it reads an item's row from the entry
-    // list in global memory, two batches ahead like the rigid form's LDS read.
-    unsigned short rows[ANM ? 2 : kPart];
-    unsigned char rows_hi[ANM ? 4 : kPart / 4];
+    // (An entry's row of the pass -- where its affine map is -- is NOT here: an item's row is read from the entry list in global
+    // memory two batches ahead of its use.  Until the end of round 5 it lay in LDS, 2.25 bytes an entry, and a job held 1024
+    // entries at most; a launch's time is A + B / (entries a job), and set-ups were a sixth of a wave's life.)
     alignas(16) float modes[ANM ? 2 * kBmModeFloats : 4];   // ANM: [ligand subtile][receptor subtile] x kBmModeFloats
 };
 template <bool ANM>
@@ -1003,7 +1002,6 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
     BmWaveSharedT<ANM> &WS = S.w[wave];
     __syncthreads();
     const uint32_t n_jobs = T->job_count[3];
-    const bool wide_rows = T->n_poses > 65536;   // (a pass of more than 2^16 rows: a GSO over hundreds of swarms)
     unsigned long long *queue = T->queue + ((size_t)blockIdx.x * kBmWaves + wave) * kBmQueueCap;   // the wave's flagged pairs
     unsigned long long *queue_blocks = queue + kBmQueuePairs;                                        // (entry, block) items with several
     uint32_t queued = 0, queued_blocks = 0;   // wave-uniform: flagged pairs listed; (entry, block) items listed
@@ -1041,42 +1039,22 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         // latency, together with the masks): lane = (receptor subtile b, atom j).
         const uint32_t roff_all = T->m.rec_rowoff[(size_t)RT * 64 + lane];           // the atom's column in a table row block
         uint32_t any_bits = 0;
-        {   // the job's block masks and rows of the pass: all loads in flight at once.  UNCONDITIONAL, from two per-lane pointers formed
-            // once: guarded by `e < hi` each of the 32 loads was a basic block of its own -- exec saved, two scalar loads of the
-            // launch arguments and a wait for them, seven scalar instructions of address arithmetic, the load -- 4 of a job set-up's
-            // 8 us.  What the lanes beyond the part's end read (the next part's entries, another tile pair's, never-written
-            // memory: the workspace has a part's room behind its end) is masked out of `bits` and otherwise unused.
-            static_assert(kBmPartEntries == 1024, "16 chunks of 64 entries");
+        {   // the job's block masks: all loads in flight at once.  UNCONDITIONAL, from a per-lane pointer formed once: guarded by
+            // `e < hi` each load was a basic block of its own -- exec saved, two scalar loads of the launch arguments and a wait
+            // for them, seven scalar instructions of address arithmetic, the load -- 4 of a job set-up's 8 us.  What the lanes
+            // beyond the part's end read (the next part's entries, another tile pair's, never-written memory: the workspace has a
+            // part's room behind its end) is masked out of `bits` and otherwise unused.
+            constexpr int kChunks = BmWaveSharedT<ANM>::kPart / 64;   // (28 chunks of 64 entries; the ANM form 16)
             const unsigned long long *mask_at = T->ent_mask + (tp * T->cap + lo + (size_t)lane);
-            const uint32_t *row_at = T->ent_row + (tp * T->cap + lo + (size_t)lane);
-            unsigned long long m[16];
-            uint32_t r[16];
+            unsigned long long m[kChunks];
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                m[k] = mask_at[k * 64];
-                r[k] = ANM ? 0u : row_at[k * 64];   // (the ANM form: per item, from the list itself)
-            }
+            for (int k = 0; k < kChunks; k++) m[k] = mask_at[k * 64];
             const uint32_t n_mine = hi - lo;   // entries of the part
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
+            for (int k = 0; k < kChunks; k++) {
                 const uint32_t bits = (uint32_t)(k * 64 + lane) < n_mine ? (uint32_t)(m[k] >> (8 * a)) & 0xffu : 0u;
-                if (k < n_chunks) {
-                    WS.row_bits[k * 64 + lane] = (unsigned char)bits;
-                    if constexpr (!ANM) WS.rows[k * 64 + lane] = (unsigned short)r[k];
-                }
+                if (k < n_chunks) WS.row_bits[k * 64 + lane] = (unsigned char)bits;
                 any_bits |= bits;
-            }
-            if (!ANM && __builtin_expect(wide_rows, 0)) {   // the rows' bits 16 and 17, four lanes to a byte (a pass of more than 2^16 rows: a GSO over hundreds of swarms)
-#pragma unroll 1
-                for (int k = 0; k < n_chunks; k++) {
-                    uint32_t rk = r[0];
-#pragma unroll
-                    for (int u = 1; u < 16; u++) rk = k == u ? r[u] : rk;
-                    uint32_t hi2 = ((rk >> 16) & 3u) << (2 * (lane & 3));
-                    hi2 |= (uint32_t)__builtin_amdgcn_mov_dpp((int)hi2, 0xb1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]: lane ^ 1
-                    hi2 |= (uint32_t)__builtin_amdgcn_mov_dpp((int)hi2, 0x4e, 0xf, 0xf, true);   // quad_perm [2,3,0,1]: lane ^ 2
-                    if ((lane & 3) == 0) WS.rows_hi[(k * 64 + lane) >> 2] = (unsigned char)hi2;
-                }
             }
         }
 #pragma unroll
@@ -1119,7 +1097,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         // scattered read-modify-writes of HBM per launch)
         long long *const my_partial = T->ent_partial + ((size_t)blockIdx.x * kBmWaves + wave) * kBmPartEntries;
         const size_t row_base_entry = tp * T->cap + lo;
-        const uint32_t *const job_rows = T->ent_row + row_base_entry;   // (ANM form: an item's row of the pass)
+        const uint32_t *const job_rows = T->ent_row + row_base_entry;   // (an item's row of the pass)
         const uint32_t dma_rowsel = (uint32_t)(lane / kRowPieces) * 4u, dma_piece = (uint32_t)(lane % kRowPieces) * 16u;   // (constants of the lane: row of the five, piece)
         if (DEBUG) dbg_t_scan += now() - dbg_tj;   // job set-up
         // a batch's results, on their way out one batch late (see run_batch)
@@ -1147,7 +1125,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 if (pending_item & 0x4000u) asm volatile("" :: "v"(pending_val), "v"(pending_row));
 #endif
 #ifndef LD_BM_DIAG_NO_PARTIAL
-                else my_partial[pending_item & 0x3ffu] = pending_val;
+                else my_partial[pending_item & (uint32_t)kBmEntryMask] = pending_val;
 #endif
             }
             pending_item = 0xffffffffu;
@@ -1178,11 +1156,12 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
             // ---- the job's entries that hold block (a, b), in entry order (all 16 chunks' bytes in flight, then the ballots)
             uint32_t n_items = 0;
             {
-                uint32_t bits16[16];
+                constexpr int kChunks = BmWaveSharedT<ANM>::kPart / 64;
+                uint32_t bits16[kChunks];
 #pragma unroll
-                for (int k = 0; k < 16; k++) bits16[k] = k < n_chunks ? (uint32_t)WS.row_bits[k * 64 + lane] : 0u;
+                for (int k = 0; k < kChunks; k++) bits16[k] = k < n_chunks ? (uint32_t)WS.row_bits[k * 64 + lane] : 0u;
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
+                for (int k = 0; k < kChunks; k++) {
                     const uint32_t bits = bits16[k];
                     const bool act = (bits >> b) & 1u;
                     const unsigned long long m = __ballot(act);
@@ -1218,22 +1197,17 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 uint32_t flags;   // bit 31: block b is the entry's FIRST of this job, bit 30: its LAST
             };
             auto read_row = [&](uint32_t item) {
-                const uint32_t el = item & 0x3ffu;
+                const uint32_t el = item & (uint32_t)kBmEntryMask;
                 RowOfItem r;
                 const uint32_t bits = (uint32_t)WS.row_bits[el];
-                if constexpr (ANM) {
-                    r.row = job_rows[el];
-                } else {
-                    r.row = (uint32_t)WS.rows[el];
-                    if (wide_rows) r.row |= (((uint32_t)WS.rows_hi[el >> 2] >> (2 * (el & 3))) & 3u) << 16;
-                }
+                r.row = job_rows[el];
                 // (x - 1) has bit 31 set exactly when x = 0, for x below 2^31
                 r.flags = (((bits & ((1u << b) - 1u)) - 1u) & 0x80000000u) | ((((bits >> (b + 1)) - 1u) >> 1) & 0x40000000u);
                 return r;
             };
             auto issue_loads = [&](uint32_t item_el, const RowOfItem &of) {
                 BatchLoads L;
-                const uint32_t item = (item_el & 0x3ffu) | (of.flags >> 16 & 0xc000u);   // entry | first << 15 | last << 14, as the code below reads it
+                const uint32_t item = (item_el & (uint32_t)kBmEntryMask) | (of.flags >> 16 & 0xc000u);   // entry | first << 15 | last << 14, as the code below reads it
                 const uint32_t row = of.row & 0x3ffffu;
                 L.item = item;
                 L.row = row;
@@ -1252,7 +1226,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 }
                 L.prev = 0;
 #ifndef LD_BM_DIAG_NO_PARTIAL
-                if (!(item & 0x8000u)) L.prev = my_partial[item & 0x3ffu];
+                if (!(item & 0x8000u)) L.prev = my_partial[item & (uint32_t)kBmEntryMask];
 #endif
                 return L;
             };
@@ -1299,7 +1273,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 constexpr uint32_t kCube = (uint32_t)(offsetof(BmShared, cube) + (size_t)WAVE * kBmCubeBytes);   // a constant LDS address
                 const int count = n_items - done >= 64u ? 64 : (int)(n_items - done);
                 const bool valid = lane < count;   // (the lanes beyond `count` repeat the first item)
-                const uint32_t el = cur.item & 0x3ffu;
+                const uint32_t el = cur.item & (uint32_t)kBmEntryMask;
                 // the lane's 8 ligand atoms posed two at a time (packed; the operations and their nesting are bm_apply's, so the
                 // culling kernel's boxes and the exact path see the same bits), relative to the block's centre
                 const v2f A0xy{cur.a0.x, cur.a0.y}, A0zw{cur.a0.z, cur.a0.w - cbx}, A1xy{cur.a1.x, cur.a1.y}, A1zw{cur.a1.z, cur.a1.w - cby};
@@ -1364,7 +1338,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                     // ... and the 480 mode components of the two subtiles are wave-uniform: delivered from LDS, 120 broadcast reads of 16
                     // bytes (one per four multiply-adds' worth of operands), four in flight
                     {
-                        const uint32_t lds_at = (uint32_t)(uintptr_t)&WS.rows[0];   // (any 1 KB of the wave's LDS: the values do not matter here)
+                        const uint32_t lds_at = (uint32_t)(uintptr_t)&WS.items[0];   // (any 1 KB of the wave's LDS: the values do not matter here)
                         asm volatile(".rept 30\n\t"
                                      "ds_read_b128 v[220:223], %6\n\tds_read_b128 v[224:227], %6 offset:16\n\tds_read_b128 v[228:231], %6 offset:32\n\tds_read_b128 v[232:235], %6 offset:48\n\t"
                                      "s_waitcnt lgkmcnt(0)\n\t"
@@ -1442,8 +1416,9 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 // a write or two, waited for the first of the loads just issued: a round trip to the L2 in every batch.)
                 asm volatile("" :: "v"(next.a0.x), "v"(next.a0.y), "v"(next.a0.z), "v"(next.a0.w), "v"(next.a1.x), "v"(next.a1.y), "v"(next.a1.z), "v"(next.a1.w),
                              "v"(next.a2.x), "v"(next.a2.y), "v"(next.a2.z), "v"(next.a2.w), "v"(next.prev));
-                // (ANM: also the row of the batch after this one, a load from the entry list: its wait belongs here too, not behind the stores below)
-                if constexpr (ANM) asm volatile("" :: "v"(next.amp[0].x), "v"(next.amp[1].x), "v"(next.amp[2].x), "v"(next.amp[3].x), "v"(next.amp[4].x), "v"(next.amp[5].x), "v"(look_row.row));
+                // (also the row of the batch after this one, a load from the entry list: its wait belongs here too, not behind the stores below)
+                asm volatile("" :: "v"(look_row.row));
+                if constexpr (ANM) asm volatile("" :: "v"(next.amp[0].x), "v"(next.amp[1].x), "v"(next.amp[2].x), "v"(next.amp[3].x), "v"(next.amp[4].x), "v"(next.amp[5].x));
                 const BatchLoads cur = next;
 #ifdef LD_BM_DIAG_WAIT   // (diagnostic builds: the drain timer holds the time a wave waits at the head of its batches for their loads)
                 if (DEBUG) dbg_t_drain += now() - dbg_tb;

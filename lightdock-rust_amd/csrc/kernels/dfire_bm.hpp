@@ -69,7 +69,9 @@ constexpr uint32_t kBmFlagged = 8 * 21;      // 168
 __host__ __device__ inline uint32_t bm_code_of_bin(uint32_t bin) { return 8 * bin; }   // bins 0..19 -> 0..152
 constexpr int kBmMarkerShift = 51;           // a lane keeps two sums of 32 pairs each: below 2^50 under it, 32 markers of at most 127 above it: 63 bits
 constexpr int kBmJobRows = 8;                // a job = (tile pair, part of its entries, ligand subtile a): the blocks (a, 0..7); one partial sum per (entry, a)
-constexpr int kBmPartEntries = 1024;         // entries of a tile pair in one job
+constexpr int kBmPartEntries = 1792;         // entries of a tile pair in one job: what a wave's share of the LDS holds at 3 bytes an entry (the block bits, the item list)
+constexpr int kBmEntryMask = 0x7ff;          // an entry's number in its part
+constexpr int kBmPassQuantum = 1024;         // poses per pass: a multiple of this
 constexpr int kBmOpsFloats = 36;             // BmModel::rec_ops: Rs[4][2], Rz[4][2], Ry[4][2], Rx[4][2], cx, cy, cz, 0
 constexpr int kBmMaxModes = 10;              // normal modes per molecule the ANM form of the path takes (the reference's examples: 10 + 10, src/dfire.rs:288-320)
 constexpr int kBmModeFloats = 8 * 3 * kBmMaxModes;   // a subtile's modes as a batch reads them: ((atom pair p * 3 + coordinate) * kBmMaxModes + mode) * 2 + atom of the pair

@@ -1049,9 +1049,9 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     // round 5 also 64 bytes of partial sums per entry, which now live in a per-wave scratch: the budgets kept their pass sizes)
     const size_t tile_pairs = (size_t)rec.n_tiles * lig.n_tiles;
     constexpr size_t kEntryBytes = 12;
-    if (tile_pairs * kBmPartEntries * kEntryBytes > ((size_t)2560 << 20)) return;   // even the smallest pass (1024 poses) would not fit 2.5 GiB: the pose-major kernels
+    if (tile_pairs * kBmPassQuantum * kEntryBytes > ((size_t)2560 << 20)) return;   // even the smallest pass (1024 poses) would not fit 2.5 GiB: the pose-major kernels
     size_t chunk = ((size_t)640 << 20) / (kEntryBytes * tile_pairs);   // a second such workspace exists while two passes are in flight
-    chunk = std::min<size_t>(kBmMaxPassPoses, std::max<size_t>(kBmPartEntries, chunk / kBmPartEntries * kBmPartEntries));
+    chunk = std::min<size_t>(kBmMaxPassPoses, std::max<size_t>(kBmPassQuantum, chunk / kBmPassQuantum * kBmPassQuantum));
     if (const char *e = std::getenv("LIGHTDOCK_BM_CHUNK")) {   // tests, A/B: any pass size that the layout can hold --
         // an entry's index (tile pair * cap + entry) travels in 32 bits (bm_block_item), and the override stays inside the 16 GiB
         // the default's guard admits for the smallest pass
