@@ -1,29 +1,35 @@
-// dfire_bm.hpp -- launch interface of the BLOCK-MAJOR DFIRE pose-energy path (K1, DFIRE, rigid molecules).
+// dfire_bm.hpp -- launch interface of the BLOCK-MAJOR DFIRE pose-energy path (K1, DFIRE: rigid molecules, and -- the ANM
+// form -- molecules that flex by normal modes, src/dfire.rs:288-320).
 //
 // Same sum as src/dfire.rs:325-345, same 64x64 / 8x8 box culling and the same f32-filter-with-exact-f64-path
 // numerics as dfire_packed.hpp, but the pair work is ordered by atom-pair BLOCK instead of by pose:
 //
 //   dfire_bm_pose    one thread per row of the pass: the pose's rotation + translation as an f32 affine map into the record
-//                    frame, [row][12], 48 bytes that stay in L2 for the whole pass
+//                    frame, [row][12], 48 bytes that stay in L2 for the whole pass; the exact path's [row][8] f64 row; clears
+//                    the pose's flag words, the pass's sums and the sequence's counters; ANM: the row's amplitudes
+//   dfire_bm_rec_boxes  (ANM) lane = row of the pass: the flexed receptor's subtile and tile boxes, f32
 //   dfire_bm_cull    persistent waves, one (ligand tile, 8 poses) item at a time: a bounding-sphere test of the tile against the
-//                    receptor's tile boxes (in LDS), then the ligand atoms posed in f32, boxes, 64x64 and 8x8 box tests; every
-//                    surviving (ligand tile, receptor tile) pair of a pose becomes one ENTRY {row of the pass, 64-bit block mask}
-//                    appended to that tile pair's list (one global atomic per tile pair per wave)
-//   dfire_bm_plan    one workgroup: every tile pair's entries cut into parts of P entries
+//                    receptor's tile boxes (in LDS; ANM: the row's own), then the ligand atoms posed in f32 (ANM: and flexed),
+//                    boxes, 64x64 and 8x8 box tests; every surviving (ligand tile, receptor tile) pair of a pose becomes one
+//                    ENTRY {row of the pass, 64-bit block mask} appended to that tile pair's list (one global atomic per
+//                    tile pair per wave)
+//   dfire_bm_plan    one workgroup: every tile pair's entries cut into equal parts of at most P entries
 //   dfire_bm_census  one wave per (tile pair, part): per ligand-subtile row the block bits of its entries -> the estimated
-//                    length of the JOB (tile pair, part, row)
+//                    length of the JOB (tile pair, part, row), and the job's 16-byte record
 //   dfire_bm_order   one workgroup: the jobs that have any work, longest first (counting sort into classes)
-//   dfire_bm_pairs   persistent workgroups of 4 independent waves (two per CU); a wave draws a job and, for each of its 8
+//   dfire_bm_pairs   persistent workgroups of 4 independent waves (two per CU); a wave takes a job and, for each of its 8
 //                    blocks (a, b): the 64 table rows T[type_i][type_j][.] of the block are staged in the wave's slice of LDS
 //                    ONCE (dense L2 -> LDS copies by LDS-DMA), the entries whose mask holds the block are compacted into
 //                    batches of 64, and a batch runs lane = pose: the lane poses the 8 ligand atoms of subtile a (uniform
-//                    local coordinates, its pose's affine map from the L2-resident [row][12] table) and walks the 64 atom
-//                    pairs of the block, whose receptor atoms and table rows are wave-uniform: E = cell-zero + 1/2 - 64 d2 in
-//                    packed f32 (coordinates relative to the receptor subtile's box centre), cell = (u32)E, code = lut[cell]
-//                    (u8, LDS), x = code - 8 with the borrow = "flagged cell" collected in a scalar mask, value = row[x]
-//                    (f64, LDS; the row's address is an instruction constant), f64 add.  No gather ever leaves the CU.
-//   dfire_bm_gather  thread = (row, ligand tile[, share of its entries]): the pose's partial sums in a fixed order -> the
-//                    [pose][1][2] partials that pose_energy_finish folds (restraint / membrane tail, src/dfire.rs:347-361)
+//                    local coordinates, its pose's affine map from the L2-resident [row][12] table; ANM: + its pose's
+//                    deformation of both subtiles, modes from LDS) and walks the 64 atom pairs of the block, whose receptor
+//                    atoms and table rows are wave-uniform: E = cell-zero + 1/2 - 64 d2 in packed f32 (coordinates relative
+//                    to the receptor subtile's box centre), cell = (u32)E, code = lut[cell] (u8, LDS), value = row[code]
+//                    (64-bit fixed point, LDS; the row's address is an instruction constant), integer add.  A flagged cell's
+//                    slot holds a MARKER that names the pair (below).  An (entry, ligand subtile)'s finished sum goes to the
+//                    pose's (row, ligand tile) sum by an integer atomic.  No gather ever leaves the CU.
+//   dfire_bm_gather  eight lanes per row: the row's ligand-tile sums + the exact path's sum -> f64 -> the [pose][1][2]
+//                    partials that pose_energy_finish folds (restraint / membrane tail, src/dfire.rs:347-361)
 //
 // Numerics: records are u = fl32(8 (x - c)); the ligand is posed by an f32 affine map whose error
 // is part of `eps`; a LUT cell (1/16 of a unit of 4 d2) whose interval, widened by eps, holds a bin step or the cutoff is

@@ -303,8 +303,8 @@ Scorer::Scorer(const ld_scorer_desc &desc) {
         use_tiled_ = !(k && std::strcmp(k, "allpairs") == 0);
         if (use_tiled_) build_tiled(desc);
         if (use_tiled_ && !(k && std::strcmp(k, "tiled") == 0)) build_packed(desc);
-        // "bm" / default: the block-major path for rigid molecules (kernels/dfire_bm.hpp); "packed": the pose-major
-        // kernel for everything (what ANM runs and LIGHTDOCK_TILED_LATENCY=1, the single-swarm CLI, use anyway)
+        // "bm" / default: the block-major path (kernels/dfire_bm.hpp; its ANM form for molecules that flex); "packed": the pose-major
+        // kernel for everything (what LIGHTDOCK_TILED_LATENCY=1, the single-swarm CLI, and the complexes build_bm declines use anyway)
         const char *latency = std::getenv("LIGHTDOCK_TILED_LATENCY");
         if (use_packed_ && !(k && std::strcmp(k, "packed") == 0) && !(latency && std::atoi(latency) > 0 && !(k && std::strcmp(k, "bm") == 0)))
             build_bm(desc);
@@ -803,7 +803,6 @@ double dfire_bm_fix_scale(double vmax, size_t reach_count, int *extra_bits_out) 
 }
 
 void Scorer::build_bm(const ld_scorer_desc &desc) {
-    // rigid molecules only: with ANM the ligand's local coordinates (and the receptor image) change per pose
     // (LIGHTDOCK_BM_DIAG_IGNORE_ANM=1: timing experiments only -- the block-major kernels on an ANM complex as if it were rigid, wrong sums)
     const char *ignore_anm = std::getenv("LIGHTDOCK_BM_DIAG_IGNORE_ANM");
     const bool diag_rigid = ignore_anm && std::atoi(ignore_anm) == 1;

@@ -115,7 +115,7 @@ class Scorer {
     void reserve_workspace(size_t n_poses, bool counts);
     void build_tiled(const ld_scorer_desc &desc);
     void build_packed(const ld_scorer_desc &desc);  // after build_tiled: shares its table, ligand and tile order
-    void build_bm(const ld_scorer_desc &desc);      // after build_packed: the block-major path for rigid molecules
+    void build_bm(const ld_scorer_desc &desc);      // after build_packed: the block-major path (rigid molecules; the ANM form for molecules that flex)
     void run_bm(size_t n, const double *d_poses, size_t stride, const uint8_t *d_active, bool counts, const uint32_t *d_list,
                 const uint32_t *d_count);
     void frame_of_receptor(const ld_molecule &rec, double centre[3], double *half) const;
