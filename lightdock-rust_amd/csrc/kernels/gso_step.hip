@@ -189,28 +189,50 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
         double total = 0.0;
         int cnt = 0;
         int chosen = i;
-        // neighbours: luciferin strictly greater, distance strictly inside the vision range
-        // (four luciferins read ahead of the tests: the loads of a trip are in flight together -- one at a time, each behind the
-        // previous candidate's branches, a thread of a live swarm waited 2 x N LDS latencies out)
-        for (int j0 = 0; j0 < N; j0 += 4) {
-            double l4[4];
+        // neighbours: luciferin strictly greater, distance strictly inside the vision range.  Four candidates a trip, their
+        // luciferins AND positions read ahead of the tests, unconditionally: the loads of a trip are in flight together -- one
+        // at a time, each behind the previous candidate's branches, a thread of a live swarm waited 2 x N LDS latencies out; with
+        // the positions still read inside the branch (round 4) it was N.  Swarms of up to 256 glowworms keep the verdicts, a bit
+        // a candidate: the roulette below then visits the neighbours only, instead of walking the swarm and taking every
+        // square root a second time.
+        const bool keep = N <= 256;
+        unsigned long long nb[4] = {0ull, 0ull, 0ull, 0ull};
+        auto scan = [&](int j_begin, int j_end, unsigned long long &found) {   // [j_begin, j_end): 64 candidates at most when `found` is kept
+            for (int j0 = j_begin; j0 < j_end; j0 += 4) {
+                double l4[4], x4[4], y4[4], z4[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) l4[u] = sl[j0 + u < N ? j0 + u : i];
+                for (int u = 0; u < 4; u++) {
+                    const int jj = j0 + u < j_end ? j0 + u : i;
+                    l4[u] = sl[jj];
+                    x4[u] = sx[jj];
+                    y4[u] = sy[jj];
+                    z4[u] = sz[jj];
+                }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + u;
-                const double lj = l4[u];
-                if (j < N && j != i && li < lj) {
-                    const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
-                    const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
-                    if (d2 > kFarD2) continue;  // sqrt(d2) > 5 >= vision range: cannot be a neighbour (exact: sqrt is monotone)
-                    const double d = sqrt(d2);
-                    if (d < vr) {
-                        total += lj - li;
-                        cnt++;
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + u;
+                    const double lj = l4[u];
+                    if (j < j_end && j != i && li < lj) {
+                        const double x2 = x4[u], y2 = y4[u], z2 = z4[u];
+                        const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
+                        if (d2 > kFarD2) continue;  // sqrt(d2) > 5 >= vision range: cannot be a neighbour (exact: sqrt is monotone)
+                        const double d = sqrt(d2);
+                        if (d < vr) {
+                            total += lj - li;
+                            cnt++;
+                            found |= 1ull << ((j - j_begin) & 63);
+                        }
                     }
                 }
             }
+        };
+        if (keep) {
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                if (w * 64 < N) scan(w * 64, N < w * 64 + 64 ? N : w * 64 + 64, nb[w]);
+        } else {
+            unsigned long long unused = 0ull;
+            scan(0, N, unused);
         }
         // one draw per glowworm whether or not it has neighbours, swarm.rs:118
         const uint64_t bits = stdrng_u64(key, (uint64_t)done * (uint64_t)N + (uint64_t)i);
@@ -218,21 +240,40 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
         if (cnt > 0) {  // while sum < r { sum += p[k]; k += 1 } -> neighbors[k-1], glowworm.rs:119-125
             double sum = 0.0;
             int k = 0;
-            for (int j = 0; j < N; j++) {
-                if (j == i) continue;
-                const double lj = sl[j];
-                if (!(li < lj)) continue;
-                const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
-                const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
-                if (d2 > kFarD2) continue;
-                const double d = sqrt(d2);
-                if (!(d < vr)) continue;
-                // k == 0 with rnd == 0.0, or running out of neighbours, is a panic in the
-                // reference (index under/overflow, probability ~2^-53); we keep the edge neighbour.
-                if (k > 0 && !(sum < rnd)) break;
-                sum += (lj - li) / total;
-                chosen = j;
-                k++;
+            if (keep) {   // the neighbours in ascending order, out of the bits
+                bool stop = false;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    unsigned long long m = nb[w];
+                    while (m != 0ull && !stop) {
+                        const int j = w * 64 + __ffsll((long long)m) - 1;
+                        m &= m - 1ull;
+                        // k == 0 with rnd == 0.0, or running out of neighbours, is a panic in the
+                        // reference (index under/overflow, probability ~2^-53); we keep the edge neighbour.
+                        if (k > 0 && !(sum < rnd)) {
+                            stop = true;
+                            break;
+                        }
+                        sum += (sl[j] - li) / total;
+                        chosen = j;
+                        k++;
+                    }
+                }
+            } else {
+                for (int j = 0; j < N; j++) {
+                    if (j == i) continue;
+                    const double lj = sl[j];
+                    if (!(li < lj)) continue;
+                    const double x2 = sx[j], y2 = sy[j], z2 = sz[j];
+                    const double d2 = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2);
+                    if (d2 > kFarD2) continue;
+                    const double d = sqrt(d2);
+                    if (!(d < vr)) continue;
+                    if (k > 0 && !(sum < rnd)) break;
+                    sum += (lj - li) / total;
+                    chosen = j;
+                    k++;
+                }
             }
         }
 
@@ -248,7 +289,7 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
 // the groups they were computed once per 8 glowworms of a wave instead of once per 64: a step of 1024 quiet swarms took twice
 // as long), the hand-over goes through LDS.  Measured on one box, 1024 swarms x 200 of 1ppe, step time quiet / 1 % alive / all
 // alive: a thread per glowworm 0.062 / 0.310 / 5.35 ms, this kernel 0.087 / 0.278 / 5.45; 64 swarms of 1k4c: 1.447 against
-// 1.396 ms.  So: this one up to 16 384 glowworms, the other beyond (round 4; round 5 moved the line to 102 400: launch_gso_step).
+// 1.396 ms.  So: this one up to 16 384 glowworms, the other beyond (round 4; round 5: gso_step_is_phased).
 __global__ __launch_bounds__(1024) void gso_movement_phased(const GsoLaunch G) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int N = G.n_glowworms;
@@ -294,17 +335,54 @@ __global__ __launch_bounds__(1024) void gso_movement_phased(const GsoLaunch G) {
         };
         double total = 0.0;
         int cnt = 0;
-        for (int j0 = 0; j0 < N; j0 += LANES) {
-            uint32_t found = (uint32_t)(__ballot(is_neighbour(j0 + sub)) >> group_shift) & ((1u << LANES) - 1u);
-            while (found) {   // in the order of j
-                const int j = j0 + __ffs(found) - 1;
-                found &= found - 1;
-                total += sl[j] - li;
-                cnt++;
+        // (swarms of up to 256 glowworms keep the verdicts, a bit a candidate, like the other kernel: the roulette then visits the
+        // neighbours only)
+        const bool keep = N <= 256;
+        unsigned long long nb[4] = {0ull, 0ull, 0ull, 0ull};
+        auto scan = [&](int j_begin, int j_end, unsigned long long &kept) {
+            for (int j0 = j_begin; j0 < j_end; j0 += LANES) {
+                uint32_t found = (uint32_t)(__ballot(j0 + sub < j_end && is_neighbour(j0 + sub)) >> group_shift) & ((1u << LANES) - 1u);
+                kept |= (unsigned long long)found << ((j0 - j_begin) & 63);
+                while (found) {   // in the order of j
+                    const int j = j0 + __ffs(found) - 1;
+                    found &= found - 1;
+                    total += sl[j] - li;
+                    cnt++;
+                }
             }
+        };
+        if (keep) {
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                if (w * 64 < N) scan(w * 64, N < w * 64 + 64 ? N : w * 64 + 64, nb[w]);
+        } else {
+            unsigned long long unused = 0ull;
+            scan(0, N, unused);
         }
         int chosen = i;
-        if (__any(cnt > 0)) {  // while sum < r { sum += p[k]; k += 1 } -> neighbors[k-1], glowworm.rs:119-125
+        if (keep) {
+            if (cnt > 0) {  // while sum < r { sum += p[k]; k += 1 } -> neighbors[k-1], glowworm.rs:119-125
+                const double rnd = s_rnd[valid ? t : 0];
+                double sum = 0.0;
+                int k = 0;
+                bool stop = false;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    unsigned long long m = nb[w];
+                    while (m != 0ull && !stop) {
+                        const int j = w * 64 + __ffsll((long long)m) - 1;
+                        m &= m - 1ull;
+                        if (k > 0 && !(sum < rnd)) {
+                            stop = true;
+                            break;
+                        }
+                        sum += (sl[j] - li) / total;
+                        chosen = j;
+                        k++;
+                    }
+                }
+            }
+        } else if (__any(cnt > 0)) {
             const double rnd = s_rnd[valid ? t : 0];
             double sum = 0.0;
             int k = 0;
@@ -344,7 +422,7 @@ __global__ __launch_bounds__(1024) void gso_movement_phased(const GsoLaunch G) {
 size_t gso_kernel_lds_bytes(const GsoLaunch &g, bool phased) { return (size_t)(phased ? 6 : 4) * g.n_glowworms * sizeof(double); }
 
 bool gso_step_is_phased(const GsoLaunch &g) {
-    // Up to 102 400 glowworms (512 swarms of 200) the phased kernel: a live swarm's step is a LATENCY (a thread of the other kernel walks
+    // Up to 65 536 glowworms (327 swarms of 200; round 5's first setting: 102 400, round 4's: 16 384) the phased kernel: a live swarm's step is a LATENCY (a thread of the other kernel walks
     // its swarm's N glowworms twice, ~100 us at N = 200 whatever the launch's size), and that latency is what a GPU's share of
     // BASELINE config 5 pays per step -- 128 swarms: 0.823 -> 0.766 ms per step, 256: 1.395 -> 1.356, 512: 2.704 -> 2.698 (round 5,
     // one box; round 4 drew the line at 16 384).  Beyond, eight times the threads cost more than the latency they save.
@@ -353,7 +431,12 @@ bool gso_step_is_phased(const GsoLaunch &g) {
     // 1024 swarms: 1 % alive 0.301 -> 0.282 ms per step, but the step in which nothing moves 0.062 -> 0.100 and everything alive
     // 5.28 -> 5.56: sixteen waves per workgroup where four do the work, and a reduction over the swarm's moved flags in
     // front of every workgroup.  Not kept.)
-    const bool small = (size_t)g.n_swarms * g.n_glowworms <= 102400;
+    // (Round 5, later: both kernels keep their verdicts for the roulette -- a bit a candidate, swarms of up to 256 glowworms -- and the
+    // thread-per-glowworm kernel reads a trip's positions ahead: a live swarm's chain fell from ~100 to ~30 us, the 1 %-alive step of
+    // 1024 swarms from 0.290 to 0.234 ms.  The line again, one box, `tools/r5_k2_shapes.sh`, single / phased, M evaluations/s:
+    // 1024 swarms 35.0 / 34.5, 512 swarms 34.8 / 34.3, 256 swarms 33.6 / 34.0, 128 swarms 29.2 / 30.0, 32 swarms 15.4 / 16.3;
+    // 64 swarms of 1k4c 7.43 / 7.53.  So: phased up to 65 536 glowworms.)
+    const bool small = (size_t)g.n_swarms * g.n_glowworms <= 65536;
     const char *mode = std::getenv("LIGHTDOCK_GSO_K2");   // diagnostics / tests: "single" / "phased" whatever the size
     const std::string m = mode ? mode : "";
     bool phased = m == "phased" || (m != "single" && small);

@@ -729,13 +729,14 @@ def _k2_env(monkeypatch, shape):
 
 
 def test_gso_odd_sizes(pkg, scorers, orc, monkeypatch):
-    """1 glowworm (never has a neighbour), 3 glowworms, more glowworms than threads in a
-    workgroup (1030 > 1024), a swarm whose LDS snapshot exceeds 64 KiB (2048: exactly 64 KiB for the thread-per-glowworm
+    """1 glowworm (never has a neighbour), 3 glowworms, swarms around the 256 glowworms up to which K2 keeps a bit per candidate
+    for the roulette, more glowworms than threads in a workgroup (1030 > 1024), a swarm whose LDS snapshot exceeds 64 KiB (2048: exactly 64 KiB for the thread-per-glowworm
     kernel, 96 KiB for the phased one; 2100): same as the oracle, in BOTH shapes of K2 (src/swarm.rs:72-126; the launch picks
     one by size, gso_step.hip, LIGHTDOCK_GSO_K2 forces one), and the two shapes' states bit for bit the same."""
     hip, cpu = scorers("1ppe")
     base = case_positions("1ppe", orc)
-    for n, steps in ((1, 3), (3, 5), (1030, 3), (2048, 2), (2100, 2)):
+    # (65, 130, 256: inside the kernels' kept-verdict range -- one, three and four words of bits --, 257: just beyond it)
+    for n, steps in ((1, 3), (3, 5), (65, 6), (130, 6), (256, 5), (257, 5), (1030, 3), (2048, 2), (2100, 2)):
         pos = pkg.synth.jitter(base, n, seed=n) if n > 200 else base[:n]
         ref = orc.GSO(cpu, pos)
         for _ in range(steps):
@@ -768,7 +769,7 @@ def test_gso_odd_sizes(pkg, scorers, orc, monkeypatch):
 @pytest.mark.parametrize("shape", K2_SHAPES)
 def test_gso_many_swarms_in_both_k2_shapes(pkg, scorers, orc, monkeypatch, shape):
     """The same batch of swarms through either shape of K2: 96 swarms x 200 glowworms and 6 x 64 (both inside the phased
-    kernel's own range of 102 400 glowworms: `single` is what gets forced) and 520 x 200 (104 000: beyond it, `phased` forced)
+    kernel's own range of 65 536 glowworms: `single` is what gets forced) and 520 x 200 (104 000: beyond it, `phased` forced)
     -- sampled swarms equal the oracle, replicated swarms stay bit-identical."""
     _k2_env(monkeypatch, shape)
     hip, cpu = scorers("1ppe")
