@@ -696,6 +696,46 @@ def test_random_molecules_match_oracle(pkg, orc, table, tmp_path, n_rec, n_lig):
         assert np.max(np.abs(got - want) / scale) < 1e-11, (env, n_rec, n_lig)
 
 
+@pytest.mark.parametrize("n_rec,n_lig,k_rec,k_lig", [(9, 7, 2, 3), (64, 8, 10, 0), (65, 63, 0, 10), (200, 130, 10, 10), (513, 65, 7, 1), (1100, 300, 10, 10)])
+def test_random_molecules_with_normal_modes_match_oracle(pkg, orc, table, tmp_path, n_rec, n_lig, k_rec, k_lig):
+    """The same with molecules that flex (src/dfire.rs:288-320): random modes, amplitudes of a few angstroms and, for a tenth
+    of the poses, forty times that (WILD for the block-major path's ANM form: everything through the exact path).  The default
+    kernel and the all-pairs kernel against the oracle; `tools/fuzz_parity.py <cases> <seed> anm` is the long form of this."""
+    rng = np.random.default_rng(7000 * n_rec + n_lig)
+    rec, lig = str(tmp_path / "rec.pdb"), str(tmp_path / "lig.pdb")
+    rec_atoms = _random_molecule(rng, n_rec, 28.0, "A", with_beads=3 if n_rec >= 64 else 0)
+    lig_atoms = _random_molecule(rng, n_lig, 18.0, "B")
+    _write_pdb(rec, rec_atoms)
+    _write_pdb(lig, lig_atoms)
+    n = 30
+    poses = np.zeros((n, 7 + k_rec + k_lig))
+    poses[:, :3] = rng.uniform(-22, 22, (n, 3))
+    poses[:4, :3] = rng.uniform(-2, 2, (4, 3))
+    q = rng.normal(size=(n, 4))
+    poses[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True) * rng.uniform(0.5, 2.0, (n, 1))
+    poses[:, 7:] = rng.normal(size=(n, k_rec + k_lig)) * 2.0
+    poses[::10, 7:] *= 40.0
+    kw = dict(rec_active=["A.%s.%d" % (rec_atoms[0][1], rec_atoms[0][3])], lig_active=["B.%s.%d" % (lig_atoms[-1][1], lig_atoms[-1][3])],
+              potential=table, use_anm=True, rec_num_anm=k_rec, lig_num_anm=k_lig,
+              rec_nmodes=(rng.normal(size=(k_rec, len(rec_atoms), 3)) * 0.4).ravel() if k_rec else None,
+              lig_nmodes=(rng.normal(size=(k_lig, len(lig_atoms), 3)) * 0.4).ravel() if k_lig else None)
+    cpu = orc.Scorer("dfire", rec, lig, **kw)
+    want = cpu.energy_rows(poses)
+    scale = np.maximum(np.abs(want), 1.0)
+    for env in ({}, {"LIGHTDOCK_DFIRE_KERNEL": "allpairs"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            hip = pkg.Scorer.from_pdb("dfire", rec, lig, **kw)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        if not env:
+            assert hip.kernel_info()["pair_kernel_name"] == "dfire_bm_pairs"
+        got = hip.energy_batch(poses)
+        assert np.max(np.abs(got - want) / scale) < 1e-11, (env, n_rec, n_lig)
+
+
 @pytest.mark.timeout(120)
 @pytest.mark.parametrize("name", ["1ppe", "1azp"])
 def test_degenerate_poses_neither_hang_nor_poison_the_batch(scorers, orc, name):

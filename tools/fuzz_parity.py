@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """GPU box: seeded random molecules of random sizes, random poses (overlapping ones included), restraints and
 membrane beads -- default DFIRE kernel against the oracle (energies) and against the all-pairs kernel
-(in-cutoff pair counts).  Usage: python tools/fuzz_parity.py [cases] [first seed]"""
+(in-cutoff pair counts).  With `anm` as third argument the molecules flex (src/dfire.rs:288-320): 0 to 10 random normal
+modes a molecule, random amplitudes -- some of them large enough to make the pose WILD for the block-major path's ANM form.
+Usage: python tools/fuzz_parity.py [cases] [first seed] [anm]"""
 import os
 import sys
 import tempfile
@@ -20,6 +22,7 @@ pkg.init(0)
 table = pkg.synth.dcparams()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+anm = len(sys.argv) > 3 and sys.argv[3] == "anm"
 dev = torch.device("cuda:0")
 worst = 0.0
 with tempfile.TemporaryDirectory() as d:
@@ -41,6 +44,20 @@ with tempfile.TemporaryDirectory() as d:
         q = rng.normal(size=(n, 4))
         poses[:, 3:] = q / np.linalg.norm(q, axis=1, keepdims=True) * rng.uniform(0.5, 2.0, (n, 1))
         kw = dict(rec_active=rec_active, lig_active=lig_active, potential=table)
+        stride = 7
+        if anm:
+            k_rec, k_lig = int(rng.integers(0, 11)), int(rng.integers(0, 11))
+            if k_rec + k_lig == 0:
+                k_lig = 3
+            # mode vectors of ~unit length per atom (like a normalised ANM mode x sqrt(atoms)), amplitudes of a few angstroms
+            rec_modes = rng.normal(size=(k_rec, len(rec_atoms), 3)) * rng.uniform(0.05, 0.6)
+            lig_modes = rng.normal(size=(k_lig, len(lig_atoms), 3)) * rng.uniform(0.05, 0.6)
+            amps = rng.normal(size=(n, k_rec + k_lig)) * rng.uniform(0.2, 3.0)
+            amps[rng.random(n) < 0.1] *= 40.0          # a tenth of the poses: absurd amplitudes (wild)
+            poses = np.ascontiguousarray(np.concatenate([poses, amps], axis=1))
+            stride = poses.shape[1]
+            kw.update(use_anm=True, rec_num_anm=k_rec, lig_num_anm=k_lig,
+                      rec_nmodes=rec_modes.ravel() if k_rec else None, lig_nmodes=lig_modes.ravel() if k_lig else None)
         cpu = orc.Scorer("dfire", rec, lig, **kw)
         want = cpu.energy_rows(poses)
         hip = pkg.Scorer.from_pdb("dfire", rec, lig, **kw)
@@ -54,13 +71,13 @@ with tempfile.TemporaryDirectory() as d:
         for s in (hip, ref):
             d_out = torch.zeros(n, dtype=torch.float64, device=dev)
             d_cnt = torch.zeros(n, dtype=torch.int32, device=dev)
-            s.energy_batch_device(n, d_poses.data_ptr(), 7, d_out.data_ptr(), None, d_cnt.data_ptr())
+            s.energy_batch_device(n, d_poses.data_ptr(), stride, d_out.data_ptr(), None, d_cnt.data_ptr())
             torch.cuda.synchronize()
             out.append((d_out.cpu().numpy(), d_cnt.cpu().numpy()))
         err = float(np.max(np.abs(hip.energy_batch(poses) - want) / np.maximum(np.abs(want), 1.0)))
         worst = max(worst, err)
         ok = err < 1e-11 and np.array_equal(out[0][1], out[1][1]) and np.max(np.abs(out[0][0] - want) / np.maximum(np.abs(want), 1.0)) < 1e-11
-        print("seed %3d  rec %4d lig %3d poses %2d  err %.2e  pairs %d  %s" % (seed, n_rec, n_lig, n, err, int(out[0][1].sum()), "ok" if ok else "MISMATCH"))
+        print("seed %3d  rec %4d lig %3d poses %2d  %s err %.2e  pairs %d  %s" % (seed, n_rec, n_lig, n, hip.kernel_info()["pair_kernel_name"], err, int(out[0][1].sum()), "ok" if ok else "MISMATCH"))
         if not ok:
             sys.exit(1)
 print("all %d cases agree; worst error %.2e of max(|E|, 1)" % (cases, worst))
