@@ -15,6 +15,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblightdock_hip.so")
+# A/B tooling (tools/ab6.sh): LIGHTDOCK_HIP_VARIANT=<name> loads lib/variants/<name>.so -- a build of the same sources with extra
+# flags, tools/build_variant.sh -- instead of the installed library, so that no script has to copy a variant over it (a diagnostic
+# build left installed by an interrupted script would give wrong sums silently).  A variant that does not exist is an error.
+if os.environ.get("LIGHTDOCK_HIP_VARIANT"):
+    LIB_PATH = os.path.join(_HERE, "lib", "variants", os.environ["LIGHTDOCK_HIP_VARIANT"] + ".so")
 CLI_PATH = os.path.join(_HERE, "bin", "lightdock-hip")
 INCLUDE_DIR = os.path.normpath(os.path.join(_HERE, "..", "include"))
 

@@ -16,6 +16,13 @@
 #include "dfire_device.hpp"
 #include "dfire_bm_batch.inc"
 
+// The LD_BM_DIAG_* blocks below are TIMING EXPERIMENTS (wrong sums by construction).  They compile only in a diagnostic build
+// (-DLD_DIAG_BUILD, which tools/build_variant.sh passes): the shipped library cannot be built with one of them by accident, and
+// tests/test_host_cpu.py checks that it carries no diagnostic switch.
+#if !defined(LD_DIAG_BUILD) && (defined(LD_BM_DIAG_ANM_COST) || defined(LD_BM_DIAG_ANM_LDS) || defined(LD_BM_DIAG_FIRST) || defined(LD_BM_DIAG_NO_ATOMIC) || defined(LD_BM_DIAG_NO_DMA) || defined(LD_BM_DIAG_NO_PAIRS) || defined(LD_BM_DIAG_NO_PARTIAL) || defined(LD_BM_DIAG_NO_TRACKED) || defined(LD_BM_DIAG_ROW_OF_LANE) || defined(LD_BM_DIAG_WAIT))
+#error "LD_BM_DIAG_* needs -DLD_DIAG_BUILD (tools/build_variant.sh)"
+#endif
+
 namespace ld {
 
 namespace {
@@ -709,7 +716,7 @@ template <bool ANM>
 struct BmWaveSharedT {
     static constexpr int kPart = ANM ? kBmAnmPartEntries : kBmPartEntries;
     unsigned char row_bits[kPart];        // per entry of the job: which of the 8 blocks (a, .) it holds
-    unsigned short items[kPart];          // the entries that hold the current block
+    unsigned short items[kPart + 64];     // the entries that hold the current block, and 64 fillers (entry 0 of the part) behind them
     // (An entry's row of the pass -- where its affine map is -- is NOT here: an item's row is read from the entry list in global
     // memory two batches ahead of its use.  Until the end of round 5 it lay in LDS, 2.25 bytes an entry, and a job held 1024
     // entries at most; a launch's time is A + B / (entries a job), and set-ups were a sixth of a wave's life.)
@@ -1142,9 +1149,10 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 static_assert(kDma == 13 && kDmaRows * kBmRowBytes == 880, "LD_BM_DMA_ASM is written for 13 copies of 880 bytes");
                 uint32_t dma_tmp[kDma];
                 unsigned long long dma_exec;
+                uint32_t dma_m0;
                 const uint32_t cube_lds = (uint32_t)(uintptr_t)S.cube[wave];
 #ifndef LD_BM_DIAG_NO_DMA   // (diagnostic builds: timing only, wrong sums)
-                LD_BM_DMA_ASM(dma_exec, dma_tmp, dma_rowsel, row_src, dma_piece, table_rows, cube_lds, 0x007fffffffffffffull, 0x00000fffffffffffull);
+                LD_BM_DMA_ASM(dma_exec, dma_m0, dma_tmp, dma_rowsel, row_src, dma_piece, table_rows, cube_lds, 0x007fffffffffffffull, 0x00000fffffffffffull);
 #endif
             }
             if (ANM) {   // the block's receptor subtile's modes -> LDS, behind the job's ligand modes
@@ -1171,6 +1179,11 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                     }
                     n_items += (uint32_t)__popcll(m);
                 }
+                // 64 fillers behind the list's end: entry 0 of the part (a real entry, so everything a lane loads for it is valid
+                // memory; what the lane computes is dropped, `valid`).  A batch's lanes beyond the end read these instead of picking
+                // "in range ? at : first" with a compare and a v_cndmask_b32 -- 23 cycles of the vector port on gfx950, five times
+                // a plain instruction (tools/microbench/valu_rate.hip, profiles/r06_valu_issue_rates.txt) -- per look-up.
+                WS.items[n_items + (uint32_t)lane] = 0;
             }
             // what a lane of a batch needs from memory, loaded one batch ahead: the pose's affine map out of the [row][12] table
             // (L2: the pass's table is 48 bytes a pose) and the entry's partial sum so far
@@ -1186,10 +1199,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
             // k + 1 are in flight (issued from a row that is already in a register), the row of batch k + 2 and the item of
             // batch k + 3 are being read -- behind the batch's own LDS traffic, whose last wait covers them.
             auto first_of = [&](uint32_t first_item) { return first_item < n_items ? first_item : 0u; };   // (beyond the block's end: its first items again)
-            auto read_item = [&](uint32_t first_item) {
-                const uint32_t at = first_item + (uint32_t)lane;
-                return (uint32_t)WS.items[at < n_items ? at : first_item];
-            };
+            auto read_item = [&](uint32_t first_item) { return (uint32_t)WS.items[first_item + (uint32_t)lane]; };   // (beyond the end: the fillers)
             // the entry's row of the pass, and in bits 30 / 31 of the same word whether block b is the entry's LAST / FIRST of this job
             // (last: the (entry, row)'s sum is complete; first: nothing to add to yet) -- from the entry's byte of block bits
             struct RowOfItem {
@@ -1267,24 +1277,27 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
             const float cbx = ops[32], cby = ops[33], cbz = ops[34];
             if (DEBUG) dbg_t_block += now() - dbg_tblk;   // block set-up
 
-            // ---- one batch: lane = entry.  WAVE = this wave's number in the workgroup, a constant of the code.
-            auto run_batch = [&](auto wave_constant, const BatchLoads &cur, uint32_t done) {
-                constexpr int WAVE = decltype(wave_constant)::value;
-                constexpr uint32_t kCube = (uint32_t)(offsetof(BmShared, cube) + (size_t)WAVE * kBmCubeBytes);   // a constant LDS address
-                const int count = n_items - done >= 64u ? 64 : (int)(n_items - done);
-                const bool valid = lane < count;   // (the lanes beyond `count` repeat the first item)
-                const uint32_t el = cur.item & (uint32_t)kBmEntryMask;
+            // ---- one batch: lane = entry.  Three pieces: the posing (code all waves share), the 64 pairs (once per wave of the
+            // workgroup: WAVE is a constant of that code, see the switch below), the markers (shared again).
+            // (Until round 6 the whole batch sat inside the switch and the next batch's loads were issued in front of it, into a second
+            // set of registers: 13 register moves a batch carried `next` into `cur`.  Posing in front of the loads frees the map's
+            // twelve registers before the loads are issued -- the loop-carried values are the same registers --, and only what the
+            // batch needs at its END (the partial so far, the item, the row) is copied.)
+            struct Posed {
+                v2f LX[4], LY[4], LZ[4], L2[4];       // atoms (2p, 2p + 1): l - c and |l - c|^2
+                v2f fRs[4], fRz[4], fRy[4], fRx[4];   // ANM: the receptor subtile's operands of THIS lane's pose
+                bool wild;
+            };
+            auto pose_batch = [&](const BatchLoads &cur, Posed &P) {
                 // the lane's 8 ligand atoms posed two at a time (packed; the operations and their nesting are bm_apply's, so the
                 // culling kernel's boxes and the exact path see the same bits), relative to the block's centre
                 const v2f A0xy{cur.a0.x, cur.a0.y}, A0zw{cur.a0.z, cur.a0.w - cbx}, A1xy{cur.a1.x, cur.a1.y}, A1zw{cur.a1.z, cur.a1.w - cby};
                 const v2f A2xy{cur.a2.x, cur.a2.y}, A2zw{cur.a2.z, cur.a2.w - cbz};
-                v2f LX[4], LY[4], LZ[4], L2[4];   // atoms (2p, 2p + 1): l - c and |l - c|^2
-                v2f fRs[4], fRz[4], fRy[4], fRx[4];   // ANM: the receptor subtile's operands of THIS lane's pose
-                bool wild = false;
+                P.wild = false;
                 if constexpr (!ANM) {
 #pragma unroll
                     for (int p = 0; p < 4; p++) {
-                        LD_BM_POSE_ASM(LX[p], LY[p], LZ[p], L2[p], A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, LocX[p], LocY[p], LocZ[p]);
+                        LD_BM_POSE_ASM(P.LX[p], P.LY[p], P.LZ[p], P.L2[p], A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, LocX[p], LocY[p], LocZ[p]);
                     }
                 } else {
                     // Both subtiles flex with the lane's pose (src/dfire.rs:288-320): atom += sum_k amplitude_k x mode_k, in the receptor's
@@ -1292,14 +1305,14 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                     // coordinate ten values a pair, two modes per 16-byte broadcast read --, the amplitudes came with the map; a
                     // packed multiply-add per mode and pair of atoms, the amplitude's half picked by the operand select.
                     const v2f *amp2 = reinterpret_cast<const v2f *>(cur.amp);   // [0..4] the receptor's amplitudes two by two, [5..9] the ligand's
-                    wild = reinterpret_cast<const float *>(cur.amp)[20] != 0.f;
+                    P.wild = reinterpret_cast<const float *>(cur.amp)[20] != 0.f;
                     const uint32_t modes_lds = (uint32_t)(uintptr_t)WS.modes;
                     {
                         v2f D[12];   // the ligand subtile's deformation: atoms (2p, 2p + 1), coordinate c at [3 p + c] (LD_BM_FLEX_ASM, dfire_bm_batch.inc)
                         LD_BM_FLEX_ASM(D, (amp2 + kBmMaxModes / 2), modes_lds);
 #pragma unroll
                         for (int p = 0; p < 4; p++) {
-                            LD_BM_POSE_FLEX_ASM(LX[p], LY[p], LZ[p], L2[p], A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, LocX[p], LocY[p], LocZ[p], D[3 * p], D[3 * p + 1], D[3 * p + 2]);
+                            LD_BM_POSE_FLEX_ASM(P.LX[p], P.LY[p], P.LZ[p], P.L2[p], A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, LocX[p], LocY[p], LocZ[p], D[3 * p], D[3 * p + 1], D[3 * p + 2]);
                         }
                     }
                     // the receptor subtile: (r - c) = Rx / 2 exactly, + the lane's deformation, then the operands as the rigid form's table
@@ -1312,28 +1325,30 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                             const v2f half{0.5f, 0.5f}, two{2.f, 2.f};
                             const v2f x = __builtin_elementwise_fma(half, Rx[q], D[3 * q]), y = __builtin_elementwise_fma(half, Ry[q], D[3 * q + 1]);
                             const v2f z = __builtin_elementwise_fma(half, Rz[q], D[3 * q + 2]);
-                            fRs[q] = __builtin_elementwise_fma(-x, x, __builtin_elementwise_fma(-y, y, __builtin_elementwise_fma(-z, z, v2f{seed, seed})));
-                            fRx[q] = x * two;
-                            fRy[q] = y * two;
-                            fRz[q] = z * two;
+                            P.fRs[q] = __builtin_elementwise_fma(-x, x, __builtin_elementwise_fma(-y, y, __builtin_elementwise_fma(-z, z, v2f{seed, seed})));
+                            P.fRx[q] = x * two;
+                            P.fRy[q] = y * two;
+                            P.fRz[q] = z * two;
                         }
                     }
                 }
-                // The batch's 64 pairs: dfire_bm_batch.inc (generated, tools/gen_bm_batch_asm.py).  Fixed-point sum: table
-                // values are integers (2^-k units, exact adds in any order); a flagged cell's slot holds the row's marker.
-                unsigned long long acc0 = 0ull, acc1 = 0ull;   // over the pairs with receptor atoms 0 2 4 6 / 1 3 5 7 of the subtile
+            };
+            // The batch's 64 pairs: dfire_bm_batch.inc (generated, tools/gen_bm_batch_asm.py).  Fixed-point sum: table values are
+            // integers (2^-k units, exact adds in any order); a flagged cell's slot holds the row's marker.
+            auto walk_batch = [&](auto wave_constant, const Posed &P, unsigned long long &acc0, unsigned long long &acc1) {
+                constexpr int WAVE = decltype(wave_constant)::value;
+                constexpr uint32_t kCube = (uint32_t)(offsetof(BmShared, cube) + (size_t)WAVE * kBmCubeBytes);   // a constant LDS address
+                (void)Rs; (void)Rz; (void)Ry; (void)Rx;   // (named here so that the generic lambda captures them: their only other use is inside an asm operand list)
 #if defined(LD_BM_DIAG_ANM_COST)
                 // Timing experiment (wrong sums): what a block-major batch would cost for molecules that FLEX per pose
                 // (src/dfire.rs:288-320: 10 + 10 normal modes) -- per lane the ligand subtile's deformation (8 atoms x 3 coordinates x 10
                 // modes = 240 multiply-adds = 120 packed), the receptor subtile's (120 packed) and its sixteen operands per lane (36
-                // packed: the batch then takes them from vector registers), and 80 more bytes per item: the pose's 20 mode amplitudes.
+                // packed: the batch then takes them from vector registers).
                 {
-                    const float4 *amp = reinterpret_cast<const float4 *>(T->poses + (size_t)(cur.row % (uint32_t)T->n_poses) * T->stride + 7);
-                    float4 q0 = amp[0], q1 = amp[1], q2 = amp[2], q3 = amp[3], q4 = amp[4];
-                    v2f t0{q0.x, q0.y}, t1{q1.x, q1.y}, t2{q2.x, q2.y}, t3{q3.x + q4.x, q3.y};
+                    v2f t0{P.LX[0].x, P.LX[1].y}, t1{P.LY[0].x, P.LY[1].y}, t2{P.LZ[0].x, P.LZ[1].y}, t3{P.L2[0].x, P.L2[1].y};
 #ifndef LD_BM_DIAG_ANM_LDS
                     asm volatile(".rept 69\n\tv_pk_fma_f32 %0, %4, %5, %0\n\tv_pk_fma_f32 %1, %4, %5, %1\n\tv_pk_fma_f32 %2, %4, %5, %2\n\tv_pk_fma_f32 %3, %4, %5, %3\n\t.endr"
-                                 : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(LX[0]), "v"(LY[0]));
+                                 : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(P.LX[0]), "v"(P.LY[0]));
 #else
                     // ... and the 480 mode components of the two subtiles are wave-uniform: delivered from LDS, 120 broadcast reads of 16
                     // bytes (one per four multiply-adds' worth of operands), four in flight
@@ -1346,7 +1361,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                                      "v_pk_fma_f32 %0, %4, v[228:229], %0\n\tv_pk_fma_f32 %1, %4, v[230:231], %1\n\tv_pk_fma_f32 %2, %5, v[232:233], %2\n\tv_pk_fma_f32 %3, %5, v[234:235], %3\n\t"
                                      ".endr\n\t"
                                      ".rept 9\n\tv_pk_fma_f32 %0, %4, %5, %0\n\tv_pk_fma_f32 %1, %4, %5, %1\n\tv_pk_fma_f32 %2, %4, %5, %2\n\tv_pk_fma_f32 %3, %4, %5, %3\n\t.endr"
-                                     : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(LX[0]), "v"(LY[0]), "v"(lds_at)
+                                     : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "v"(P.LX[0]), "v"(P.LY[0]), "v"(lds_at)
                                      : "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "memory");
                     }
 #endif
@@ -1355,39 +1370,53 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                     for (int q = 0; q < 4; q++) {
                         vRs[q] = Rs[q] + t0 * v2f{0.f, 0.f}; vRz[q] = Rz[q] + t1 * v2f{0.f, 0.f}; vRy[q] = Ry[q] + t2 * v2f{0.f, 0.f}; vRx[q] = Rx[q] + t3 * v2f{0.f, 0.f};
                     }
-                    LD_BM_BATCH_ASM_V(acc0, acc1, vRs, vRz, vRy, vRx, L2, LZ, LY, LX, kCube);
+                    LD_BM_BATCH_ASM_V(acc0, acc1, vRs, vRz, vRy, vRx, P.L2, P.LZ, P.LY, P.LX, kCube);
                 }
 #elif !defined(LD_BM_DIAG_NO_PAIRS)
                 if constexpr (ANM) {
-                    LD_BM_BATCH_ASM_V(acc0, acc1, fRs, fRz, fRy, fRx, L2, LZ, LY, LX, kCube);
+                    LD_BM_BATCH_ASM_V(acc0, acc1, P.fRs, P.fRz, P.fRy, P.fRx, P.L2, P.LZ, P.LY, P.LX, kCube);
                 } else {
-                    LD_BM_BATCH_ASM(acc0, acc1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX, kCube);
+                    LD_BM_BATCH_ASM(acc0, acc1, Rs, Rz, Ry, Rx, P.L2, P.LZ, P.LY, P.LX, kCube);
                 }
 #else
-                asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(L2[0]), "v"(L2[1]), "v"(L2[2]), "v"(L2[3]), "v"(LX[0]), "v"(LY[0]), "v"(LZ[0]), "s"(Rs[0]), "s"(Rx[3]));
+                asm volatile("" : "+v"(acc0), "+v"(acc1) : "v"(P.L2[0]), "v"(P.L2[1]), "v"(P.L2[2]), "v"(P.L2[3]), "v"(P.LX[0]), "v"(P.LY[0]), "v"(P.LZ[0]), "s"(Rs[0]), "s"(Rx[3]));
 #endif
+            };
+            // what a batch keeps of its loads until its END: the entry's partial so far, its item and row of the pass
+            auto finish_batch = [&](long long cur_prev, uint32_t cur_item, uint32_t cur_row, bool wild, unsigned long long acc0, unsigned long long acc1, uint32_t done) {
+                const int count = n_items - done >= 64u ? 64 : (int)(n_items - done);
+                // the lanes beyond `count` hold a filler (entry 0 of the part): nothing of theirs leaves.  All-ones for them, by
+                // arithmetic (a compare and a v_cndmask_b32 per use cost the vector port 27 cycles, this 9)
+                // (through an asm statement: written as C++ the compiler turns the shift back into the compare and the select)
+                uint32_t invalid;
+                asm("v_ashrrev_i32 %0, 31, %1" : "=v"(invalid) : "v"(count - 1 - lane));
+                const uint32_t el = cur_item & (uint32_t)kBmEntryMask;
                 // each sum = marker bits + the true sum, |true sum| < 2^50 (32 pairs; the scale is chosen for that)
                 // (the marker bits live in the sums' upper words -- bit 51 is bit 19 there, and rounding by 2^50 never carries out of
                 // the lower word: 32-bit arithmetic does what 64-bit shifts and subtractions did in twice the instructions)
                 static_assert(kBmMarkerShift > 33, "the markers sit in the upper word");
                 constexpr int kHiShift = kBmMarkerShift - 32;
                 const int mark0 = ((int)(uint32_t)(acc0 >> 32) + (1 << (kHiShift - 1))) >> kHiShift, mark1 = ((int)(uint32_t)(acc1 >> 32) + (1 << (kHiShift - 1))) >> kHiShift;
-                const unsigned long long both = acc0 + acc1;
-                const long long part = (long long)(((unsigned long long)((uint32_t)(both >> 32) - ((uint32_t)(mark0 + mark1) << kHiShift)) << 32) | (uint32_t)both);
-                const int mark = mark0 | mark1;   // (one of them 0: the other's value)
-                // (ANM: a wild pose -- amplitudes beyond what the f32 arithmetic's error bound covers -- sends its whole block to the exact
-                // path through the list of (entry, block) items, and nothing of what it summed here counts)
-                const bool any_flagged = valid && (mark != 0 || wild);
-                const bool one = any_flagged && !wild && (mark0 == 0 || mark1 == 0) && mark >= 64 && mark < 128, several = any_flagged && !one;
-                const unsigned long long m1 = __ballot(one), m2 = __ballot(several);
+                // the true sum = both sums less their marker bits: a subtraction in the upper word only (wrap-around there is the 64-bit
+                // subtraction's), folded into the entry's partial so far -- one 64-bit add, one 32-bit subtract
+                const unsigned long long marker_bits = (unsigned long long)((uint32_t)(mark0 + mark1) << kHiShift) << 32;
+                // A sum's marker bits are 0 (no flagged pair among its 32), 64 + pair (one) or at least 128 (several): so the two sums'
+                // marker bits ADDED are 0, 64 + pair, or at least 128 -- one range test each instead of tests of both sums and their
+                // combinations.  (ANM: a wild pose -- amplitudes beyond what the f32 arithmetic's error bound covers -- sends its whole
+                // block to the exact path through the list of (entry, block) items, and nothing of what it summed here counts.)
+                uint32_t marks = (uint32_t)(mark0 + mark1);
+                if constexpr (ANM) marks = wild ? 128u : marks;
+                marks &= ~invalid;
+                const bool one = marks - 64u < 64u, several = marks >= 128u;
+                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(one), m2 = __builtin_amdgcn_ballot_w64(several);
                 // the lane's one pair in a flagged cell (0.1 % of all pairs; some lane of nearly every batch has one): the exact path.
                 // Like the lane's sum, the item leaves at the start of the NEXT batch (flush_pending): stored here, just before the
                 // loop's wait for the next batch's loads, that wait was for this store's acknowledgement -- in every batch.
                 pending_push = 0xffffffffu;
                 if (one) {
-                    const int pair = (int)mark - 64;
+                    const int pair = (int)marks - 64;
                     pending_push = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-                    pending_push_item = bm_pair_item(cur.row, ls * 8 + (pair >> 3), RT * 64 + b * 8 + (pair & 7));
+                    pending_push_item = bm_pair_item(cur_row, ls * 8 + (pair >> 3), RT * 64 + b * 8 + (pair & 7));
                 }
                 queued += (uint32_t)__popcll(m1);
                 if (__builtin_expect(m2 != 0ull, 0)) {
@@ -1400,9 +1429,10 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 // The lane's sum goes out at the start of the NEXT batch (flush_pending): memory operations complete in order, and
                 // the wait for the next batch's loads at the loop's top would wait for a store or atomic issued here, just before it,
                 // as well -- a round trip to the L2 per batch.  Issued in front of the following loads, it has a whole batch to complete.
-                pending_val = cur.prev + (wild ? 0ll : part);
-                pending_item = valid ? cur.item : 0xffffffffu;
-                pending_row = cur.row;
+                if constexpr (ANM) pending_val = wild ? cur_prev : (long long)((unsigned long long)cur_prev + acc0 + acc1 - marker_bits);
+                else pending_val = (long long)((unsigned long long)cur_prev + acc0 + acc1 - marker_bits);
+                pending_item = cur_item | invalid;
+                pending_row = cur_row;
             };
             for (uint32_t done = 0; done < n_items; done += 64) {
                 if (DEBUG) dbg_batches++;
@@ -1419,7 +1449,6 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 // (also the row of the batch after this one, a load from the entry list: its wait belongs here too, not behind the stores below)
                 asm volatile("" :: "v"(look_row.row));
                 if constexpr (ANM) asm volatile("" :: "v"(next.amp[0].x), "v"(next.amp[1].x), "v"(next.amp[2].x), "v"(next.amp[3].x), "v"(next.amp[4].x), "v"(next.amp[5].x));
-                const BatchLoads cur = next;
 #ifdef LD_BM_DIAG_WAIT   // (diagnostic builds: the drain timer holds the time a wave waits at the head of its batches for their loads)
                 if (DEBUG) dbg_t_drain += now() - dbg_tb;
 #endif
@@ -1434,18 +1463,25 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                     if (tracked) row[0] = row[1] = marker;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // the posing consumes the map: its registers are free for the next batch's loads
+                Posed P;
+                pose_batch(next, P);
+                const long long cur_prev = next.prev;
+                const uint32_t cur_item = next.item, cur_row = next.row;
                 // (in the code all waves share, and unconditional -- the block's last batch asks for its first items again -- so that the
                 // loads land in the registers the next trip reads them from: behind a branch the compiler moved them there
                 // right away, i.e. waited for them)
                 next = issue_loads(look_item, look_row);
                 const RowOfItem in_row = read_row(look2_item);                  // batch k + 2's row
                 const uint32_t in_item = read_item(first_of(done + 192u));      // batch k + 3's item
+                unsigned long long acc0 = 0ull, acc1 = 0ull;   // over the pairs with receptor atoms 0 2 4 6 / 1 3 5 7 of the subtile
                 switch (wave) {
-                    case 0: run_batch(std::integral_constant<int, 0>{}, cur, done); break;
-                    case 1: run_batch(std::integral_constant<int, 1>{}, cur, done); break;
-                    case 2: run_batch(std::integral_constant<int, 2>{}, cur, done); break;
-                    default: run_batch(std::integral_constant<int, 3>{}, cur, done); break;
+                    case 0: walk_batch(std::integral_constant<int, 0>{}, P, acc0, acc1); break;
+                    case 1: walk_batch(std::integral_constant<int, 1>{}, P, acc0, acc1); break;
+                    case 2: walk_batch(std::integral_constant<int, 2>{}, P, acc0, acc1); break;
+                    default: walk_batch(std::integral_constant<int, 3>{}, P, acc0, acc1); break;
                 }
+                finish_batch(cur_prev, cur_item, cur_row, P.wild, acc0, acc1, done);
                 look_item = look2_item;
                 look_row = in_row;
                 look2_item = in_item;
@@ -1575,9 +1611,11 @@ hipError_t launch_bm_cull(const BmLaunch &t, hipStream_t stream) {
 
 static unsigned bm_pairs_groups(const BmLaunch &t) {   // persistent: what the chip holds
     unsigned groups = (t.pairs_groups > 0 ? (unsigned)t.pairs_groups : 256u) * kBmGroupsPerCu;
-    if (const char *e = std::getenv("LIGHTDOCK_BM_HALF_OCCUPANCY")) {   // diagnostics: one workgroup per CU (one wave per SIMD)
+#ifdef LD_DIAG_BUILD   // (diagnostic builds only, tools/build_variant.sh)
+    if (const char *e = std::getenv("LIGHTDOCK_BM_HALF_OCCUPANCY")) {   // one workgroup per CU (one wave per SIMD)
         if (std::atoi(e) == 1) groups /= kBmGroupsPerCu;
     }
+#endif
     return groups;
 }
 

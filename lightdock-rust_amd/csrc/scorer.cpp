@@ -248,7 +248,11 @@ Scorer::Scorer(const ld_scorer_desc &desc) {
     hipDeviceProp_t prop;
     hip_check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
     n_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !std::getenv("LIGHTDOCK_ALLOW_ANY_ARCH"))
+    bool arch_ok = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+#ifdef LD_DIAG_BUILD   // (diagnostic builds only, tools/build_variant.sh: the shipped library has no switch that waives the check)
+    if (std::getenv("LIGHTDOCK_ALLOW_ANY_ARCH")) arch_ok = true;
+#endif
+    if (!arch_ok)
         throw Error(LD_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
 
     // own non-blocking stream: kernels of this handle never serialise with the legacy default
@@ -740,13 +744,24 @@ size_t dfire_bm_reach_count(const double *xyz, size_t n, double reach) {
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (size_t i = 0; i < n; i++)
         for (int c = 0; c < 3; c++) {
+            if (!std::isfinite(xyz[3 * i + c])) return n;   // (no cell for such an atom: the trivial bound)
             lo[c] = std::min(lo[c], xyz[3 * i + c]);
             hi[c] = std::max(hi[c], xyz[3 * i + c]);
         }
     // the atoms binned in cells of side rho: a probe reads the 27 cells around its own
+    // (Guards in double, before any cast: an outlier atom -- a 9999.999 dummy coordinate -- or a NaN makes the extent absurd; the
+    // probe grid below has (rho / h)^3 ~ 340 points per cell, so it is the PROBE count that bounds the search: beyond ~10^7 probes
+    // the trivial bound n is returned instead -- only coarser, never wrong.)
+    double cells = 1.0, n_probes = 1.0;
+    for (int c = 0; c < 3; c++) {
+        const double ext = hi[c] - lo[c];
+        if (!(ext >= 0.0) || !(ext < 1e6)) return n;
+        cells *= std::floor(ext / rho) + 1.0;
+        n_probes *= std::floor(ext / h) + 1.0;
+    }
+    if (cells > 1e7 || n_probes > 1e7) return n;
     int dim[3];
     for (int c = 0; c < 3; c++) dim[c] = (int)std::floor((hi[c] - lo[c]) / rho) + 1;
-    if ((double)dim[0] * dim[1] * dim[2] > 1e8) return n;   // (absurdly sparse: give the trivial bound)
     auto cell_of = [&](const double *p, int *ijk) {
         for (int c = 0; c < 3; c++) ijk[c] = std::min(dim[c] - 1, std::max(0, (int)std::floor((p[c] - lo[c]) / rho)));
     };
@@ -803,9 +818,14 @@ double dfire_bm_fix_scale(double vmax, size_t reach_count, int *extra_bits_out) 
 }
 
 void Scorer::build_bm(const ld_scorer_desc &desc) {
-    // (LIGHTDOCK_BM_DIAG_IGNORE_ANM=1: timing experiments only -- the block-major kernels on an ANM complex as if it were rigid, wrong sums)
+#ifdef LD_DIAG_BUILD
+    // (diagnostic builds only, tools/build_variant.sh -- LIGHTDOCK_BM_DIAG_IGNORE_ANM=1: timing experiments, the block-major kernels
+    // on an ANM complex as if it were rigid, wrong sums.  The shipped library does not read the variable.)
     const char *ignore_anm = std::getenv("LIGHTDOCK_BM_DIAG_IGNORE_ANM");
     const bool diag_rigid = ignore_anm && std::atoi(ignore_anm) == 1;
+#else
+    constexpr bool diag_rigid = false;
+#endif
     const TiledSoA &rec = tiled_rec_soa_, &lig = tiled_lig_soa_;
     // Molecules that flex per pose (src/dfire.rs:288-320): the ANM form of the kernels, for up to kBmMaxModes modes a molecule and a
     // receptor below 8192 atoms (the fixed-point scale's reach count is then the atom count whatever the deformation).

@@ -15,7 +15,7 @@ of the one per add the compiler's schedule had.  Written by hand because at two 
 issues, scalar or wait, costs it a turn.
 
 Temporaries are fixed registers (clobbered): v[220:235] table values, v[236:243] / v[244:251]
-cells and codes, v[252:255] the two packed E.  Operands: acc, acc1 (+v, 64 bit: the sums over the pairs with the even / odd receptor atom of a record), Rs0..3 Rz0..3 Ry0..3 Rx0..3 (the block's receptor
+cells and codes, v[252:255] the two packed E.  Operands: acc, acc1 (outputs, 64 bit: the sums over the pairs with the even / odd receptor atom of a record), Rs0..3 Rz0..3 Ry0..3 Rx0..3 (the block's receptor
 records, wave-uniform: scalar register pairs), l2/lz/ly/lx0..3 = the values of the lane's ligand atoms (2p, 2p + 1), cube = LDS address of the wave's cube.
 """
 import os
@@ -57,11 +57,12 @@ def stage_b(h):
 def stage_c(h):
     # two running sums, taken in turn (acc: the pairs with receptor atom 2g, acc1: 2g + 1): an add depends on the one two before it,
     # and each sum covers 32 pairs only -- one more bit for the fixed point under the markers
+    # (a sum's FIRST add takes 0 as its addend: the sums are outputs of the statement, no two v_mov_b64 in front of every batch)
     ts = 220   # (one set: the adds of stage h - 2 are issued before the reads of stage h - 1 that overwrite it)
     out = []
     for k in range(8):
         acc = "%[acc]" if k % 2 == 0 else "%[acc1]"
-        out.append("v_lshl_add_u64 %s, v[%d:%d], 0, %s" % (acc, ts + 2 * k, ts + 2 * k + 1, acc))
+        out.append("v_lshl_add_u64 %s, v[%d:%d], 0, %s" % (acc, ts + 2 * k, ts + 2 * k + 1, "0" if h == 0 and k < 2 else acc))
     return out
 
 
@@ -111,7 +112,9 @@ def flex_block():
     reg = lambda i: "v[%d:%d]" % (220 + 4 * (i % RING), 223 + 4 * (i % RING))
     lo = lambda i: "v[%d:%d]" % (220 + 4 * (i % RING), 221 + 4 * (i % RING))
     hi = lambda i: "v[%d:%d]" % (222 + 4 * (i % RING), 223 + 4 * (i % RING))
-    lines = ["ds_read_b128 %s, %%[modes] offset:%d" % (reg(i), 16 * i) for i in range(RING)]
+    # (the counted waits below are right only if nothing else is outstanding on lgkmcnt at entry -- scalar loads return out of
+    # order and share the counter; the block's scalar loads of rec_ops are not inputs of the FIRST statement: wait for all here)
+    lines = ["s_waitcnt lgkmcnt(0)"] + ["ds_read_b128 %s, %%[modes] offset:%d" % (reg(i), 16 * i) for i in range(RING)]
     for i in range(N):
         issued = min(N, i + RING)
         lines.append("s_waitcnt lgkmcnt(%d)" % (issued - i - 1))
@@ -137,12 +140,13 @@ def dma_block():
     compiler made thirteen rounds of bpermute / s_waitcnt lgkmcnt(0) / copy, each a full LDS latency: 1.7 of a block set-up's
     2.5 us.)  Operands: ROWSEL = 4 * (row of the five), PIECE = 16 * piece (constants of the lane), SRC, TABLE (64-bit, uniform:
     the row table), CUBE (uniform: the LDS address of the wave's cube), M55 / M44 (the lanes of an instruction: 55, the last
-    one's 44 -- its fifth row would be row 64).  Clobbers m0."""
+    one's 44 -- its fifth row would be row 64).  m0 and exec are saved and restored inside the statement (m0 is a reserved register: naming it
+    as a clobber is a warning and "may not be preserved"), scc -- set by s_add_u32 -- is a named clobber."""
     # (the bpermutes with every lane active: a lane that is switched off pushes nothing, and reading it returns 0)
     lines = []
     for t in range(13):
         lines.append("ds_bpermute_b32 %%[t%d], %%[rowsel], %%[src] offset:%d" % (t, 20 * t))
-    lines += ["s_mov_b64 %[save], exec", "s_mov_b64 exec, %[m55]", "s_waitcnt lgkmcnt(0)"]
+    lines += ["s_mov_b64 %[save], exec", "s_mov_b32 %[savem0], m0", "s_mov_b64 exec, %[m55]", "s_waitcnt lgkmcnt(0)"]
     for t in range(13):
         if t == 12:
             lines.append("s_mov_b64 exec, %[m44]")
@@ -151,7 +155,8 @@ def dma_block():
         lines.append("s_nop 0")
         lines.append("global_load_lds_dwordx4 %%[t%d], %%[table]" % t)
     lines.append("s_mov_b64 exec, %[save]")
-    outs = ['[save] "=&s"(SAVE)'] + ['[t%d] "=&v"(TMP[%d])' % (t, t) for t in range(13)]
+    lines.append("s_mov_b32 m0, %[savem0]")
+    outs = ['[save] "=&s"(SAVE)', '[savem0] "=&s"(SAVEM0)'] + ['[t%d] "=&v"(TMP[%d])' % (t, t) for t in range(13)]
     ins = ['[rowsel] "v"(ROWSEL)', '[src] "v"(SRC)', '[piece] "v"(PIECE)', '[table] "s"(TABLE)', '[cube] "s"(CUBE)', '[m55] "s"(M55)', '[m44] "s"(M44)']
     return lines, outs, ins
 
@@ -189,7 +194,7 @@ def main():
         f.write("// %d instructions: %d vector, %d LDS, %d waits.\n" % (len(lines), sum(l.startswith("v_") for l in lines), sum(l.startswith("ds_") for l in lines), sum(l.startswith("s_waitcnt") for l in lines)))
         for macro, ops in (("LD_BM_BATCH_ASM", ops_in), ("LD_BM_BATCH_ASM_V", operands("v"))):
             f.write("#define %s(SUM0, SUM1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX, CUBE) \\\n  asm volatile( \\\n" % macro + body + " \\\n")
-            f.write('    : [acc] "+v"(SUM0), [acc1] "+v"(SUM1) \\\n    : ' + ", \\\n      ".join(ops) + ', \\\n      [cube] "n"(CUBE) \\\n')
+            f.write('    : [acc] "=&v"(SUM0), [acc1] "=&v"(SUM1) \\\n    : ' + ", \\\n      ".join(ops) + ', \\\n      [cube] "n"(CUBE) \\\n')
             f.write("    : " + clobbers + ', "memory")\n\n')
         plines, pouts, pins = pose_block()
         f.write("\n// two of the lane's 8 ligand atoms posed: %d packed instructions\n" % len(plines))
@@ -208,9 +213,10 @@ def main():
         f.write("    : " + ", \\\n      ".join(xouts) + " \\\n    : " + ", \\\n      ".join(xins) + " \\\n    : " + ", ".join(xclob) + ")\n")
         dlines, douts, dins = dma_block()
         f.write("\n// a block's 64 table rows -> the wave's cube: 13 ds_bpermute in flight, one wait, 13 LDS-DMA copies\n")
-        f.write("#define LD_BM_DMA_ASM(SAVE, TMP, ROWSEL, SRC, PIECE, TABLE, CUBE, M55, M44) \\\n  asm volatile( \\\n")
+        f.write("#define LD_BM_DMA_ASM(SAVE, SAVEM0, TMP, ROWSEL, SRC, PIECE, TABLE, CUBE, M55, M44) \\\n  asm volatile( \\\n")
         f.write(" \\\n".join('    "%s\\n\\t"' % l for l in dlines) + " \\\n")
-        f.write("    : " + ", \\\n      ".join(douts) + " \\\n    : " + ", \\\n      ".join(dins) + ' \\\n    : "memory")\n')
+        # (s_add_u32 sets scc: named, or the compiler may keep a compare's result live across the statement; m0: saved and restored)
+        f.write("    : " + ", \\\n      ".join(douts) + " \\\n    : " + ", \\\n      ".join(dins) +  ' \\\n    : "memory", "scc")\n')
     print("wrote", os.path.normpath(path), len(lines), "+", len(plines), "instructions")
 
 

@@ -3,9 +3,15 @@ against the CPU oracle on the same inputs, against the reference's committed out
 (tests/golden), and through size-independent properties at full batch sizes.
 
 Tolerances.  BASELINE.json's north star asks for 1e-4 relative on energies and exact
-glowworm indices.  The kernels do all geometry in f64 in the reference's operation order, so
-the only difference to the CPU is the order of the += over pairs: we hold the energies to
-REL_TOL = 1e-9 (observed ~1e-13) and everything integer to equality.
+glowworm indices.  Every DECISION a pair takes -- cutoff, distance bin, interface flag -- is the
+reference's f64 decision bit for bit: the DNA / PYDOCK and all-f64 DFIRE kernels do their geometry in
+f64 in the reference's operation order; the default DFIRE kernels (block-major `dfire_bm_*`, pose-major
+`dfire_packed_pairs`) reach the same decisions through an f32 filter whose every doubtful pair is
+redone in f64 (the in-cutoff pair COUNT of a pose is asserted equal to the
+oracle's).  What differs from the CPU is the SUM: its order (f64 kernels: `rel_err`, ~1e-13 observed)
+or, on the block-major path, 64-bit fixed-point table values rounded once to 2^-40 (`bm_err`: an
+absolute error model, 2-7e-12 observed).  We hold the energies to REL_TOL = 1e-9 and everything
+integer to equality.
 """
 import os
 import shutil
@@ -37,7 +43,9 @@ def bm_err(got, want):
     2^-(44-e) (2^e >= the table's largest |value|; 2^-40 for the synthetic table) and added exactly, in any order: an
     ABSOLUTE error model, |err| <= N_pairs * 2^-(45-e) * 0.0157 (src/dfire.rs:347) -- below 8e-10 for 1k4c's 114 k pairs
     in the worst case, 2-4e-12 observed (tools/err_probe.py) -- whatever the size of the energy, which is
-    4.7 - 0.0157 * sum and passes through zero."""
+    4.7 - 0.0157 * sum and passes through zero.  BM_ATOL = 1e-11 is an EMPIRICAL allowance, two to five times what is observed and far
+    below the model's worst case: a legitimate worst-case batch could exceed it and would have to be judged against the model
+    (bench.py derives its allowance from the model: P_cut * 2^-(45-e) * 0.0157 per pose)."""
     return np.max(np.maximum(np.abs(got - want) - BM_ATOL, 0.0) / np.maximum(np.abs(want), 1e-9))
 
 
@@ -262,12 +270,13 @@ def test_pass_smaller_than_the_batch_by_construction(pkg, orc, table, tmp_path):
     assert bm_err(e[idx], cpu.energy_rows(poses[idx])) < REL_TOL
 
 
-@pytest.mark.parametrize("name,steps", [("1ppe", 30), ("1azp", 12), ("1k4c", 6)])
+@pytest.mark.parametrize("name,steps", [("1ppe", 100), ("1azp", 12), ("1k4c", 6)])
 def test_gso_steps_match_oracle(pkg, scorers, orc, name, steps):
     """K1 + K2 step by step against the oracle's GSO: neighbour counts, chosen neighbour ids and
-    moved flags exact; luciferin / vision / scoring / poses to rounding.  1k4c is the headline system: the block-major K1 fed
-    by K2's compacted list of the glowworms that moved, 52 ligand tiles, the membrane penalty (src/dfire.rs:355-359) on some
-    of the swarm's poses."""
+    moved flags exact AT EVERY STEP; luciferin / vision / scoring / poses to rounding.  1ppe runs the reference's full length
+    (100 steps, src/lib.rs:46-58; tools/long_run_check.py is the 400-step version).  1k4c is the headline
+    system: the block-major K1 fed by K2's compacted list of the glowworms that moved, 52 ligand tiles, the membrane penalty
+    (src/dfire.rs:355-359) on some of the swarm's poses."""
     hip, cpu = scorers(name)
     poses = case_positions(name, orc)
     if name == "1k4c":
@@ -837,15 +846,19 @@ def test_gso_dfire_with_anm_2uuy(pkg, scorers, orc):
     """DFIRE with receptor + ligand ANM (per-pose receptor image, src/dfire.rs:304-320) inside
     the GSO loop, incl. the ANM move step (src/glowworm.rs:159-188)."""
     hip, cpu = scorers("2uuy")
+    assert hip.kernel_info()["pair_kernel_name"] == "dfire_bm_pairs"     # the block-major path's ANM form: `bm_err` is its measure
     poses = case_positions("2uuy", orc)[:96]
     gso, ref = pkg.GSO(hip, poses), orc.GSO(cpu, poses)
-    for step in range(12):
+    for step in range(1, 41):   # (tools/long_run_check_anm.py is the 200-step version)
         gso.step()
         ref.step()
-    a, b = gso.read(0), ref.state()
-    assert np.array_equal(a["n_neighbors"], b["n_neighbors"]) and np.array_equal(a["target"], b["target"])
-    assert rel_err(a["scoring"], b["scoring"]) < REL_TOL
-    assert np.max(np.abs(a["poses"] - b["poses"])) < 1e-12
+        a, b = gso.read(0), ref.state()
+        assert np.array_equal(a["n_neighbors"], b["n_neighbors"]), "step %d" % step
+        assert np.array_equal(a["target"], b["target"]), "step %d" % step
+        assert np.array_equal(a["moved"], b["moved"]), "step %d" % step
+        assert err_for("2uuy")(a["scoring"], b["scoring"]) < REL_TOL
+        assert np.max(np.abs(a["poses"] - b["poses"])) < 1e-12
+    assert gso.num_evals == ref.num_evals
 
 
 def test_library_before_torch_shares_one_hip_runtime():

@@ -1,7 +1,9 @@
 # A/B of the library variants under lightdock-rust_amd/lib/variants over several bench workloads (GPU box)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
+shopt -s nullglob
 L=lightdock-rust_amd/lib
 cp $L/liblightdock_hip.so /tmp/keep.so
+trap 'cp /tmp/keep.so $L/liblightdock_hip.so' EXIT INT TERM   # an interrupted run must not leave a variant installed; tools/ab6.sh never installs one
 for w in "$@"; do
   for round in 1 2; do
     for v in $L/variants/*.so; do

@@ -1,9 +1,11 @@
 # round 5: A/B of the prebuilt variants on one box: the 1k4c headline, gso-1ppe, and the 1 %-alive GSO step
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
+shopt -s nullglob
 L=lightdock-rust_amd/lib
 bash tools/ab.sh
 bash tools/ab.sh --workload gso-1ppe
 cp $L/liblightdock_hip.so /tmp/keep2.so
+trap 'cp /tmp/keep2.so $L/liblightdock_hip.so' EXIT INT TERM   # an interrupted run must not leave a variant installed; tools/ab6.sh never installs one
 for round in 1 2; do
 for v in $L/variants/*.so; do
   cp $v $L/liblightdock_hip.so

@@ -1,7 +1,9 @@
 # round 5: A/B of the prebuilt variants with a kernel trace of the default command each (culling / pair kernel times), then the bench lines
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
+shopt -s nullglob
 L=lightdock-rust_amd/lib
 cp $L/liblightdock_hip.so /tmp/keep3.so
+trap 'cp /tmp/keep3.so $L/liblightdock_hip.so' EXIT INT TERM   # an interrupted run must not leave a variant installed; tools/ab6.sh never installs one
 for v in $L/variants/*.so; do
   n=$(basename $v .so); cp $v $L/liblightdock_hip.so
   out=gpurun_out/r05abt/$n; mkdir -p $out

@@ -1,9 +1,11 @@
 # round 5: kernel trace of the default bench command for every prebuilt variant (or the installed library when there is none)
 # usage (GPU box): bash tools/r5_trace.sh <tag>
 tag=${1:-r05t}
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
+shopt -s nullglob
 L=lightdock-rust_amd/lib
 cp $L/liblightdock_hip.so /tmp/keep.so
+trap 'cp /tmp/keep.so $L/liblightdock_hip.so' EXIT INT TERM   # an interrupted run must not leave a variant installed; tools/ab6.sh never installs one
 vs=$(ls $L/variants/*.so 2>/dev/null); [ -z "$vs" ] && vs=/tmp/keep.so
 for v in $vs; do
   n=$(basename $v .so); cp $v $L/liblightdock_hip.so

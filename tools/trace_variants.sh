@@ -1,8 +1,10 @@
 # GPU box: rocprofv3 --kernel-trace averages of the block-major kernels for every prebuilt library variant
 # usage: bash tools/trace_variants.sh [bench args]
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
+shopt -s nullglob
 L=lightdock-rust_amd/lib
 cp $L/liblightdock_hip.so /tmp/keep.so
+trap 'cp /tmp/keep.so $L/liblightdock_hip.so' EXIT INT TERM   # an interrupted run must not leave a variant installed; tools/ab6.sh never installs one
 for v in $L/variants/*.so; do
   cp $v $L/liblightdock_hip.so
   n=$(basename $v .so); rm -rf /tmp/tr_$n
