@@ -19,7 +19,7 @@
 // The LD_BM_DIAG_* blocks below are TIMING EXPERIMENTS (wrong sums by construction).  They compile only in a diagnostic build
 // (-DLD_DIAG_BUILD, which tools/build_variant.sh passes): the shipped library cannot be built with one of them by accident, and
 // tests/test_host_cpu.py checks that it carries no diagnostic switch.
-#if !defined(LD_DIAG_BUILD) && (defined(LD_BM_DIAG_ANM_COST) || defined(LD_BM_DIAG_ANM_LDS) || defined(LD_BM_DIAG_FIRST) || defined(LD_BM_DIAG_NO_ATOMIC) || defined(LD_BM_DIAG_NO_DMA) || defined(LD_BM_DIAG_NO_PAIRS) || defined(LD_BM_DIAG_NO_PARTIAL) || defined(LD_BM_DIAG_NO_TRACKED) || defined(LD_BM_DIAG_ROW_OF_LANE) || defined(LD_BM_DIAG_WAIT))
+#if !defined(LD_DIAG_BUILD) && (defined(LD_BM_DIAG_ANM_COST) || defined(LD_BM_DIAG_ANM_LDS) || defined(LD_BM_DIAG_FIRST) || defined(LD_BM_DIAG_NO_ATOMIC) || defined(LD_BM_DIAG_NO_DMA) || defined(LD_BM_DIAG_NO_PAIRS) || defined(LD_BM_DIAG_NO_PARTIAL) || defined(LD_BM_DIAG_NO_POSE) || defined(LD_BM_DIAG_NO_TRACKED) || defined(LD_BM_DIAG_ROW_OF_LANE) || defined(LD_BM_DIAG_WAIT))
 #error "LD_BM_DIAG_* needs -DLD_DIAG_BUILD (tools/build_variant.sh)"
 #endif
 
@@ -49,6 +49,13 @@ __device__ __forceinline__ float bm_cull_gap2(v2f lx, v2f ly, v2f lz, const BmCu
     const v2f dx = r.x + lx, dy = r.y + ly, dz = r.z + lz;
     const float gx = fmaxf(0.0f, fmaxf(dx.x, dx.y)), gy = fmaxf(0.0f, fmaxf(dy.x, dy.y)), gz = fmaxf(0.0f, fmaxf(dz.x, dz.y));
     return gx * gx + gy * gy + gz * gz;
+}
+// select by a mask held in a scalar register pair (v_cndmask_b32_e64): 4.4 cycles of the vector port; the compiler's usual form, with the
+// mask in VCC (v_cndmask_b32_e32), 23 (measured, tools/microbench/valu_rate.hip)
+__device__ __forceinline__ float bm_select(unsigned long long mask, float if_set, float if_clear) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
 }
 // v_writelane_b32 (value, lane: wave-uniform; the other lanes keep `old`): this compiler has the intrinsic but no builtin for it
 extern "C" __device__ int bm_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
@@ -109,10 +116,10 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
         const size_t words = (size_t)T->m.lig.n_tiles * T->m.rec_n_tiles + kBmCounters + kBmCullQueueWords;
         for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < words; k += (size_t)gridDim.x * 256) T->tp_count[k] = 0u;
     }
-    {   // the (row, ligand tile) sums of the pass: one contiguous range, cleared by consecutive threads (a thread clearing its own
-        // row's n_lt words wrote 64 different lines per store)
+    {   // the (ligand tile, row) sums of the pass, [ligand tile][cap rows]: per ligand tile the first `rows` words, cleared by consecutive
+        // threads
         const size_t sums = rows * (size_t)T->m.lig.n_tiles;
-        for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < sums; k += (size_t)gridDim.x * 256) T->tile_sum[k] = 0;
+        for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < sums; k += (size_t)gridDim.x * 256) T->tile_sum[(k / rows) * T->cap + k % rows] = 0;
     }
     for (size_t listed = (size_t)blockIdx.x * 256 + threadIdx.x; listed < rows; listed += (size_t)gridDim.x * 256) {
         const long long p = bm_pose_of(T, listed);
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                 const float gx = fmaxf(0.f, fmaxf(tb.lox - sx, sx - tb.hix));
                 const float gy = fmaxf(0.f, fmaxf(tb.loy - sy, sy - tb.hiy));
                 const float gz = fmaxf(0.f, fmaxf(tb.loz - sz, sz - tb.hiz));
-                any_near = __ballot(base + lane < n_rt && gx * gx + gy * gy + gz * gz <= reach * reach) != 0ull;
+                any_near = __builtin_amdgcn_ballot_w64(base + lane < n_rt && gx * gx + gy * gy + gz * gz <= reach * reach) != 0ull;
             }
             if (!any_near) {
                 if (COUNT && lane == 0) T->tile_tested[(listed0 + g) * (size_t)n_lt + lt] = 0;
@@ -487,12 +494,21 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
 
         // An atom outside the frame is more than the cutoff away from every receptor atom (the frame holds the receptor's
         // box + 16 A): it joins no box; the pairs it still meets inside blocks of its subtile read "miss", as they must.
-        BoxRegs sub = lane_box(valid && inside, fx, fy, fz);
+        // The lane's point as a box, an excluded lane's as the empty box (lo = +inf, hi = -inf): ONE select -- a penalty of 0 or
+        // +inf added for the minima, subtracted for the maxima -- instead of six.  (A select on VCC, `v_cndmask_b32_e32`, holds the
+        // vector port for 23 cycles on gfx950, five plain instructions' worth -- tools/microbench/valu_rate.hip,
+        // profiles/r06_valu_issue_rates.txt --; the form with the mask in a scalar register pair costs 4.4: bm_select.  An excluded
+        // lane whose coordinate is itself infinite or NaN yields NaN on one side: v_min / v_max return the other operand, i.e. it
+        // still joins no box.)
+        const float pen = bm_select(__builtin_amdgcn_ballot_w64(valid && inside), 0.0f, INFINITY);
+        BoxRegs sub{fx + pen, fy + pen, fz + pen, fx - pen, fy - pen, fz - pen};
         box_reduce8(sub);
-        {   // widen: the f32 positions are within box_pad of the exactly posed ones
-            box_widen(sub);
-            sub.lox -= pad; sub.loy -= pad; sub.loz -= pad;
-            sub.hix += pad; sub.hiy += pad; sub.hiz += pad;
+        {   // widen: the f32 positions are within box_pad of the exactly posed ones; the boxes are built from fl32(u), the true u within
+            // 2^-24 |u| of it: |u| <= ubound for every atom in a box, so 2^-22 ubound on top of the pad is outwards (the relative
+            // widening atom by atom, box_widen, was 18 vector instructions a pose and tile; an infinite side stays infinite)
+            const float wide = pad + 2.384185791015625e-07f * ubound;
+            sub.lox -= wide; sub.loy -= wide; sub.loz -= wide;
+            sub.hix += wide; sub.hiy += wide; sub.hiz += wide;
         }
         const v2f sub_x{-sub.hix, sub.lox}, sub_y{-sub.hiy, sub.loy}, sub_z{-sub.hiz, sub.loz};
         BoxRegs whole = sub;   // (widening is monotone: the union of the widened subtile boxes IS the widened tile box)
@@ -506,7 +522,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
             bool tile_near = false;
             if (base == 0) tile_near = lane < n_rt && box_gap2(whole, my_tile) <= kBmBoxCut;
             else if (base + lane < n_rt) tile_near = box_gap2(whole, tile_at(base + lane)) <= kBmBoxCut;
-            unsigned long long rtmask = __ballot(tile_near);
+            unsigned long long rtmask = __builtin_amdgcn_ballot_w64(tile_near);
             if (rtmask) {
                 // one surviving tile at a time, the next one's subtile boxes loaded while this one's are tested (the last trip loads
                 // its own again: no branch around the loads)
@@ -520,9 +536,9 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                     rtmask &= rtmask - 1;
                     nb_next = sub_at(RT_next * 8 + bj);
 #ifdef LD_BM_DIAG_NO_TRACKED   // (diagnostic builds: timing only, wrong sums -- no block with a receptor subtile that holds a tracked atom, i.e. 1k4c's beads)
-                    const unsigned long long smask = __ballot(bm_cull_gap2(sub_x, sub_y, sub_z, nb) <= kBmBoxCut && T->m.rec_sub_tracked[RT * 8 + bj] == 0);
+                    const unsigned long long smask = __builtin_amdgcn_ballot_w64(bm_cull_gap2(sub_x, sub_y, sub_z, nb) <= kBmBoxCut && T->m.rec_sub_tracked[RT * 8 + bj] == 0);
 #else
-                    const unsigned long long smask = __ballot(bm_cull_gap2(sub_x, sub_y, sub_z, nb) <= kBmBoxCut);  // bit = ligand subtile (lane >> 3) * 8 + receptor subtile
+                    const unsigned long long smask = __builtin_amdgcn_ballot_w64(bm_cull_gap2(sub_x, sub_y, sub_z, nb) <= kBmBoxCut);  // bit = ligand subtile (lane >> 3) * 8 + receptor subtile
 #endif
                     if (smask) {   // hit `held` of this ballot stays in lane `held` until the ballot's tiles are done
                         held_lo = (uint32_t)bm_writelane((int)(uint32_t)smask, (int)held, (int)held_lo);
@@ -753,7 +769,13 @@ struct BmWaveCtx {
 // bm_exact_pairs: lane = flagged pair: exact_pair (f64, the reference's operation order, dfire_device.hpp), its value added
 // to the pose's fixed-point sum by an atomic, its interface flags set.  The lists live in global memory (in practice a few
 // lines per wave that never leave the L2).
-constexpr int kBmDrainAt = 256;   // flagged pairs a wave collects before it evaluates them
+#ifndef LD_BM_DRAIN_AT
+#define LD_BM_DRAIN_AT 256
+#endif
+#ifndef LD_BM_EXACT_U
+#define LD_BM_EXACT_U 4
+#endif
+constexpr int kBmDrainAt = LD_BM_DRAIN_AT;   // flagged pairs a wave collects before it evaluates them
 __device__ __forceinline__ unsigned long long bm_pair_item(uint32_t row, int la, int ra) {
     return (unsigned long long)row | (unsigned long long)la << 32 | (unsigned long long)ra << 48;
 }
@@ -765,7 +787,7 @@ __device__ __forceinline__ void bm_exact_pairs(BmArgs *T, unsigned long long *qu
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     // Four pairs per lane and trip, phase by phase: the four items, then their rows, then everything the pairs read -- a
     // pair is a chain of five dependent loads, and one at a time the chains were most of this function's time.
-    constexpr int U = 4;
+    constexpr int U = LD_BM_EXACT_U;
     const ExactCtx ex0 = bm_exact_ctx(T, 0);
     const size_t flag_words = (size_t)(T->m.rec_flag_words + T->m.lig.flag_words);
     for (uint32_t base = 0; base < n_pairs; base += 64 * U) {
@@ -973,7 +995,7 @@ __device__ __forceinline__ uint32_t bm_recheck(BmArgs *T, const unsigned char *l
                 const uint32_t cell = bm_cell(Rs, Rz, Ry, Rx, l2[i], lz[i], ly[i], lx[i]);
                 const uint32_t code = lut[cell];
                 const bool hit = act && (wild || code == kBmFlagged || (near_code != 0xffffffffu && code <= near_code));   // (a wild pose: every pair, the exact path decides)
-                const unsigned long long m = __ballot(hit);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
                 if (hit) {
                     const uint32_t at = n_pairs + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     queue[at] = bm_pair_item(row, ls * 8 + i, RT * 64 + b * 8 + 2 * q + h);
@@ -1000,7 +1022,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
     if ((uint32_t)(uintptr_t)&S != 0u) __builtin_trap();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_rt = T->m.rec_n_tiles, n_lt = T->m.lig.n_tiles;
+    const int n_rt = T->m.rec_n_tiles;
     if (T->job_count[3] == 0) return;   // no job (a GSO step in which nothing moved): not 512 workgroups' copies of the LUT either -- that launch took 55 us
     {
         const uint8_t *lut = T->count_mode ? T->m.lut_full : T->m.lut;
@@ -1107,13 +1129,17 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         const uint32_t *const job_rows = T->ent_row + row_base_entry;   // (an item's row of the pass)
         const uint32_t dma_rowsel = (uint32_t)(lane / kRowPieces) * 4u, dma_piece = (uint32_t)(lane % kRowPieces) * 16u;   // (constants of the lane: row of the five, piece)
         if (DEBUG) dbg_t_scan += now() - dbg_tj;   // job set-up
-        // a batch's results, on their way out one batch late (see run_batch)
-        // (the sums' address and stride, opaque to the compiler: read through the kernel arguments at their use they were two scalar
-        // loads and a wait for them inside every batch's write-out)
+        // a batch's results, on their way out one batch late (flush_pending)
+        // (the sums' address, opaque to the compiler: read through the kernel arguments at its use it was two scalar loads and a wait
+        // for them inside every batch's write-out)
         typedef __attribute__((address_space(1))) unsigned long long global_u64;
-        unsigned long long job_tile_sum_bits = (unsigned long long)(uintptr_t)(T->tile_sum + lt);
-        uint32_t job_n_lt = (uint32_t)n_lt;
-        asm volatile("" : "+s"(job_tile_sum_bits), "+s"(job_n_lt));
+        // the pass's (ligand tile, row) sums: [ligand tile][row of the pass] -- the lanes of a batch are entries of ONE tile pair, in
+        // the order the culling kernel listed them: runs of up to 8 consecutive rows (its items are 8 poses), so with the rows
+        // contiguous a run's atomics are ONE 64-byte request at the memory side, where the atomics execute, instead of one each
+        // (as [row][ligand tile], until round 6, every lane's atomic was a request of its own: MI355X_MICROARCH.md "Global float
+        // atomics": 64 lanes in 64 different rows run at a seventeenth of the rate of contiguous ones)
+        unsigned long long job_tile_sum_bits = (unsigned long long)(uintptr_t)(T->tile_sum + (size_t)lt * T->cap);
+        asm volatile("" : "+s"(job_tile_sum_bits));
         global_u64 *const job_tile_sum = (global_u64 *)job_tile_sum_bits;   // (a GLOBAL pointer: as a generic one the atomic became a flat instruction)
         long long pending_val = 0;
         uint32_t pending_item = 0xffffffffu, pending_row = 0;
@@ -1123,11 +1149,13 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
             if (pending_push != 0xffffffffu) queue[pending_push] = pending_push_item;
             pending_push = 0xffffffffu;
             // The (entry, ligand subtile)'s sum is complete with the entry's last block of the job: it goes to the pose's
-            // (row, ligand tile) sum by an integer atomic -- order-free, and no gather over 24 M scattered partial sums afterwards.
+            // (ligand tile, row) sum by an integer atomic -- order-free, and no gather over 24 M scattered partial sums afterwards.
+            // (All of a job's atomics in one burst at the job's end, out of the scratch, was measured in round 6: 6.0 against 6.35 M
+            // evaluations/s -- tools/experiments/r06_atomics_at_job_end.patch.)
             if (pending_item != 0xffffffffu) {
                 // (LD_BM_DIAG_*: diagnostic builds -- timing only, wrong sums: what the kernel takes without one of its memory streams)
 #ifndef LD_BM_DIAG_NO_ATOMIC
-                if (pending_item & 0x4000u) __hip_atomic_fetch_add(job_tile_sum + (size_t)pending_row * job_n_lt, (unsigned long long)pending_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pending_item & 0x4000u) __hip_atomic_fetch_add(job_tile_sum + pending_row, (unsigned long long)pending_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
                 if (pending_item & 0x4000u) asm volatile("" :: "v"(pending_val), "v"(pending_row));
 #endif
@@ -1172,7 +1200,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 for (int k = 0; k < kChunks; k++) {
                     const uint32_t bits = bits16[k];
                     const bool act = (bits >> b) & 1u;
-                    const unsigned long long m = __ballot(act);
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(act);
                     if (act) {   // (the entry's number only: whether this is its first or last block of the job is worked out per batch, read_row)
                         const uint32_t at = n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                         WS.items[at] = (unsigned short)(k * 64 + lane);
@@ -1200,7 +1228,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
             // batch k + 3 are being read -- behind the batch's own LDS traffic, whose last wait covers them.
             auto first_of = [&](uint32_t first_item) { return first_item < n_items ? first_item : 0u; };   // (beyond the block's end: its first items again)
             auto read_item = [&](uint32_t first_item) { return (uint32_t)WS.items[first_item + (uint32_t)lane]; };   // (beyond the end: the fillers)
-            // the entry's row of the pass, and in bits 30 / 31 of the same word whether block b is the entry's LAST / FIRST of this job
+            // the entry's row of the pass, and in bits 30 / 31 of a second word whether block b is the entry's LAST / FIRST of this job
             // (last: the (entry, row)'s sum is complete; first: nothing to add to yet) -- from the entry's byte of block bits
             struct RowOfItem {
                 uint32_t row;     // the entry's row of the pass (ANM form: as loaded from the entry list -- nothing may be computed from it before the loop's wait)
@@ -1295,10 +1323,15 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
                 const v2f A2xy{cur.a2.x, cur.a2.y}, A2zw{cur.a2.z, cur.a2.w - cbz};
                 P.wild = false;
                 if constexpr (!ANM) {
+#ifndef LD_BM_DIAG_NO_POSE
 #pragma unroll
                     for (int p = 0; p < 4; p++) {
                         LD_BM_POSE_ASM(P.LX[p], P.LY[p], P.LZ[p], P.L2[p], A0xy, A0zw, A1xy, A1zw, A2xy, A2zw, LocX[p], LocY[p], LocZ[p]);
                     }
+#else   // (diagnostic builds: timing only, wrong sums -- what ANY scheme that reuses an entry's posed atoms across a job's blocks could save at most)
+#pragma unroll
+                    for (int p = 0; p < 4; p++) { P.LX[p] = A0xy; P.LY[p] = A1xy; P.LZ[p] = A2xy; P.L2[p] = A0zw; }
+#endif
                 } else {
                     // Both subtiles flex with the lane's pose (src/dfire.rs:288-320): atom += sum_k amplitude_k x mode_k, in the receptor's
                     // frame.  The modes of the two subtiles lie in LDS in the order they are read here -- per pair of atoms and
@@ -1530,7 +1563,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
 }
 
 // ---------------------------------------------------------------------------------------------
-// dfire_bm_gather: eight lanes = row of the pass: the pose's (row, ligand tile) sums -- integers, filled by the pair kernel's
+// dfire_bm_gather: two lanes = row of the pass: the pose's (ligand tile, row) sums -- integers, filled by the pair kernel's
 // atomics, each below 2^61 -- added as f64 in a fixed order (a pose's total can pass 63 bits for an extreme table), plus the
 // exact path's sum.  A counting launch (count_mode) sums ones.
 // ---------------------------------------------------------------------------------------------
@@ -1538,27 +1571,24 @@ __global__ __launch_bounds__(256) void dfire_bm_gather(const BmLaunch launch_arg
     BmArgs *T = LD_BM_ARGS;
     const int n_lt = T->m.lig.n_tiles;
     const size_t n_rows = bm_rows(T);
-    // eight lanes per row, each every eighth tile sum (consecutive lanes read consecutive words); the sums are integers, their f64
-    // images added over the eight lanes in a fixed tree
-    const int sub = (int)threadIdx.x & 7;
-    const size_t rows_per_trip = (size_t)gridDim.x * 32;
-    for (size_t first = (size_t)blockIdx.x * 32; first < n_rows; first += rows_per_trip) {   // (whole waves stay together for the shuffles)
-        const size_t row = first + threadIdx.x / 8;
+    // a wave = 32 rows x 2: lane l and lane l + 32 share row l, each every other ligand tile; the sums lie [ligand tile][row], so a
+    // load's 32 lanes read 32 consecutive words.  The sums are integers, their f64 images added in a fixed order.
+    const int lane = (int)threadIdx.x & 63, half = lane >> 5;
+    const size_t rows_per_trip = (size_t)gridDim.x * 128;
+    for (size_t first = (size_t)blockIdx.x * 128; first < n_rows; first += rows_per_trip) {   // (whole waves stay together for the shuffle)
+        const size_t row = first + (threadIdx.x >> 6) * 32 + (size_t)(lane & 31);
         const bool valid = row < n_rows;
         const long long pp = valid ? bm_pose_of(T, row) : -1;
         double units = 0.0;
         uint32_t tested = 0;
         if (pp >= 0)
-            for (int lt = sub; lt < n_lt; lt += 8) {
-                units += (double)T->tile_sum[row * (size_t)n_lt + lt];
+            for (int lt = half; lt < n_lt; lt += 2) {
+                units += (double)T->tile_sum[(size_t)lt * T->cap + row];   // [ligand tile][row of the pass]
                 if (T->count_mode && T->tile_tested) tested += T->tile_tested[row * (size_t)n_lt + lt];
             }
-#pragma unroll
-        for (int off = 4; off > 0; off >>= 1) {
-            units += __shfl_xor(units, off, 64);
-            tested += (uint32_t)__shfl_xor((int)tested, off, 64);
-        }
-        if (pp < 0 || sub != 0) continue;
+        units += __shfl_xor(units, 32, 64);
+        tested += (uint32_t)__shfl_xor((int)tested, 32, 64);
+        if (pp < 0 || half != 0) continue;
         const size_t pose = (size_t)pp;
         units += (double)T->exact_fix[row];
         if (T->count_mode) {   // (pair counts stay far below 2^53: exact)
@@ -1637,7 +1667,7 @@ hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
 
 hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    hipLaunchKernelGGL(dfire_bm_gather, dim3((unsigned)std::min<size_t>((t.n_poses + 31) / 32, 8192)), dim3(256), 0, stream, t);   // 8 lanes per row
+    hipLaunchKernelGGL(dfire_bm_gather, dim3((unsigned)std::min<size_t>((t.n_poses + 127) / 128, 8192)), dim3(256), 0, stream, t);   // 2 lanes per row
     return hipGetLastError();
 }
 

@@ -209,7 +209,8 @@ struct BmLaunch {
     unsigned long long *queue = nullptr;   // [waves of dfire_bm_pairs][kBmQueueCap]: pairs waiting for the exact path
     int pairs_groups = 0;                  // CUs dfire_bm_pairs / dfire_bm_cull may fill (0: the 256 of an MI355X)
     unsigned long long *debug = nullptr;   // diagnostics (LIGHTDOCK_BM_DEBUG): per wave of dfire_bm_pairs {start, end (100 MHz), jobs, batches, ...}
-    long long *tile_sum = nullptr;         // [row][lig tiles], zeroed by dfire_bm_pose: the pair kernel adds every finished (entry, ligand subtile) sum (fixed point)
+    long long *tile_sum = nullptr;         // [lig tile][cap rows], zeroed by dfire_bm_pose: the pair kernel adds every finished (entry, ligand subtile) sum (fixed point);
+                                           // rows contiguous: a batch's lanes are runs of consecutive rows, whose atomics then share 64-byte requests
     uint32_t *tile_tested = nullptr;       // [row][lig tiles]: 8x8 blocks let through (diagnostics) or nullptr
     long long *exact_fix = nullptr;        // [row], zeroed by dfire_bm_pose: exact-path sum, fixed point
     uint32_t *exact_pairs = nullptr;       // [row]: pairs recomputed in f64 (diagnostics) or nullptr

@@ -21,32 +21,35 @@ records, wave-uniform: scalar register pairs), l2/lz/ly/lx0..3 = the values of t
 import os
 
 ROW = 176
+T0 = 220   # first of the block's 36 fixed temporaries (tools/microbench/gen_mfma_batch.py moves them for its three-waves-per-SIMD form)
 
 
 def stage_a(h):
-    g, i0, cs = h // 2, 4 * (h % 2), 236 + 8 * (h % 2)
+    g, i0, cs = h // 2, 4 * (h % 2), T0 + 16 + 8 * (h % 2)
+    e0, e1, e2, e3 = T0 + 32, T0 + 33, T0 + 34, T0 + 35
+    ea, eb = "v[%d:%d]" % (e0, e1), "v[%d:%d]" % (e2, e3)
     out = []
     for t in range(2):
         i = i0 + 2 * t
         # ligand atoms i, i + 1 = the two halves of the pair registers l2/lz/ly/lx[i / 2]: op_sel broadcasts the half
         p = i // 2
         out += [
-            "v_pk_add_f32 v[252:253], %%[rs%d], %%[l2%d] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" % (g, p),
-            "v_pk_add_f32 v[254:255], %%[rs%d], %%[l2%d] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" % (g, p),
-            "v_pk_fma_f32 v[252:253], %%[rz%d], %%[lz%d], v[252:253] op_sel:[0,0,0] op_sel_hi:[1,0,1]" % (g, p),
-            "v_pk_fma_f32 v[254:255], %%[rz%d], %%[lz%d], v[254:255] op_sel:[0,1,0] op_sel_hi:[1,1,1]" % (g, p),
-            "v_pk_fma_f32 v[252:253], %%[ry%d], %%[ly%d], v[252:253] op_sel:[0,0,0] op_sel_hi:[1,0,1]" % (g, p),
-            "v_pk_fma_f32 v[254:255], %%[ry%d], %%[ly%d], v[254:255] op_sel:[0,1,0] op_sel_hi:[1,1,1]" % (g, p),
-            "v_pk_fma_f32 v[252:253], %%[rx%d], %%[lx%d], v[252:253] op_sel:[0,0,0] op_sel_hi:[1,0,1]" % (g, p),
-            "v_pk_fma_f32 v[254:255], %%[rx%d], %%[lx%d], v[254:255] op_sel:[0,1,0] op_sel_hi:[1,1,1]" % (g, p),
+            "v_pk_add_f32 %s, %%[rs%d], %%[l2%d] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" % (ea, g, p),
+            "v_pk_add_f32 %s, %%[rs%d], %%[l2%d] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" % (eb, g, p),
+            "v_pk_fma_f32 %s, %%[rz%d], %%[lz%d], %s op_sel:[0,0,0] op_sel_hi:[1,0,1]" % (ea, g, p, ea),
+            "v_pk_fma_f32 %s, %%[rz%d], %%[lz%d], %s op_sel:[0,1,0] op_sel_hi:[1,1,1]" % (eb, g, p, eb),
+            "v_pk_fma_f32 %s, %%[ry%d], %%[ly%d], %s op_sel:[0,0,0] op_sel_hi:[1,0,1]" % (ea, g, p, ea),
+            "v_pk_fma_f32 %s, %%[ry%d], %%[ly%d], %s op_sel:[0,1,0] op_sel_hi:[1,1,1]" % (eb, g, p, eb),
+            "v_pk_fma_f32 %s, %%[rx%d], %%[lx%d], %s op_sel:[0,0,0] op_sel_hi:[1,0,1]" % (ea, g, p, ea),
+            "v_pk_fma_f32 %s, %%[rx%d], %%[lx%d], %s op_sel:[0,1,0] op_sel_hi:[1,1,1]" % (eb, g, p, eb),
         ]
-        out += ["v_cvt_u32_f32 v%d, v%d" % (cs + 4 * t + k, 252 + k) for k in range(4)]
+        out += ["v_cvt_u32_f32 v%d, v%d" % (cs + 4 * t + k, e0 + k) for k in range(4)]
     out += ["ds_read_u8 v%d, v%d" % (cs + k, cs + k) for k in range(8)]
     return out
 
 
 def stage_b(h):
-    g, i0, cs, ts = h // 2, 4 * (h % 2), 236 + 8 * (h % 2), 220
+    g, i0, cs, ts = h // 2, 4 * (h % 2), T0 + 16 + 8 * (h % 2), T0
     out = []
     for k in range(8):
         row = (i0 + k // 2) * 8 + 2 * g + (k % 2)
@@ -58,7 +61,7 @@ def stage_c(h):
     # two running sums, taken in turn (acc: the pairs with receptor atom 2g, acc1: 2g + 1): an add depends on the one two before it,
     # and each sum covers 32 pairs only -- one more bit for the fixed point under the markers
     # (a sum's FIRST add takes 0 as its addend: the sums are outputs of the statement, no two v_mov_b64 in front of every batch)
-    ts = 220   # (one set: the adds of stage h - 2 are issued before the reads of stage h - 1 that overwrite it)
+    ts = T0   # (one set: the adds of stage h - 2 are issued before the reads of stage h - 1 that overwrite it)
     out = []
     for k in range(8):
         acc = "%[acc]" if k % 2 == 0 else "%[acc1]"

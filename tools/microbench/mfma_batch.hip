@@ -134,6 +134,84 @@ __global__ __launch_bounds__(kWaves * 64, 2) void run(const Args A) {
     }
 }
 
+// ---- three waves per SIMD (timing only): the same batch in 168 registers (temporaries at v132..v167), workgroups of
+// 53 KB -- three per CU --, two waves sharing a cube (what a kernel with room for twelve cubes per CU would not need to do)
+struct Shared3 {
+    unsigned char lut[kLut];
+    unsigned char cube[2][kCube];
+    unsigned char pad[54000 - kLut - 2 * kCube];
+};
+template <int CUBE>
+__device__ __forceinline__ void batch3(unsigned long long &acc0, unsigned long long &acc1, const v2f (&Rs)[4], const v2f (&Rz)[4], const v2f (&Ry)[4],
+                                       const v2f (&Rx)[4], const v2f (&L2)[4], const v2f (&LZ)[4], const v2f (&LY)[4], const v2f (&LX)[4]) {
+    MB_BATCH_VALU_T132;
+}
+__global__ __launch_bounds__(kWaves * 64, 3) void run3(const Args A) {
+    __shared__ __attribute__((aligned(16))) Shared3 S;
+    if ((unsigned)(uintptr_t)&S != 0u) __builtin_trap();
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < kLut / 16; i += kWaves * 64) reinterpret_cast<uint4 *>(S.lut)[i] = reinterpret_cast<const uint4 *>(A.lut)[i];
+    for (int i = tid; i < 2 * kCube / 16; i += kWaves * 64) reinterpret_cast<uint4 *>(S.cube[0])[i] = reinterpret_cast<const uint4 *>(A.rows)[i % (kCube / 16)];
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    typedef const __attribute__((address_space(4))) float const_f32;
+    const_f32 *ops = (const_f32 *)(uintptr_t)A.rec;
+    v2f Rs[4], Rz[4], Ry[4], Rx[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        Rs[q] = v2f{ops[2 * q], ops[2 * q + 1]};
+        Rz[q] = v2f{ops[8 + 2 * q], ops[9 + 2 * q]};
+        Ry[q] = v2f{ops[16 + 2 * q], ops[17 + 2 * q]};
+        Rx[q] = v2f{ops[24 + 2 * q], ops[25 + 2 * q]};
+    }
+    const v2f LocX[4] = {{-1.5f, 0.5f}, {1.25f, -0.75f}, {0.25f, 1.75f}, {-0.5f, 0.0f}}, LocY[4] = {{0.5f, -1.0f}, {1.5f, 0.25f}, {-1.75f, 0.75f}, {1.0f, -0.25f}};
+    const v2f LocZ[4] = {{1.0f, 1.5f}, {-0.5f, -1.25f}, {0.75f, 0.0f}, {-1.5f, 0.5f}};
+    unsigned long long total = 0ull;
+    const unsigned gthread = blockIdx.x * (kWaves * 64) + tid;
+    for (int b = 0; b < A.batches; b++) {
+        const unsigned m = (gthread * 2654435761u + (unsigned)b * 40503u) % A.n_maps;
+        const float4 *ap = reinterpret_cast<const float4 *>(A.maps) + (size_t)m * 3;
+        const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+        v2f LX[4], LY[4], LZ[4], L2[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const v2f X = LocX[p], Y = LocY[p], Z = LocZ[p];
+            LX[p] = __builtin_elementwise_fma(v2f{a0.x, a0.x}, X, __builtin_elementwise_fma(v2f{a0.y, a0.y}, Y, __builtin_elementwise_fma(v2f{a0.z, a0.z}, Z, v2f{a0.w, a0.w})));
+            LY[p] = __builtin_elementwise_fma(v2f{a1.x, a1.x}, X, __builtin_elementwise_fma(v2f{a1.y, a1.y}, Y, __builtin_elementwise_fma(v2f{a1.z, a1.z}, Z, v2f{a1.w, a1.w})));
+            LZ[p] = __builtin_elementwise_fma(v2f{a2.x, a2.x}, X, __builtin_elementwise_fma(v2f{a2.y, a2.y}, Y, __builtin_elementwise_fma(v2f{a2.z, a2.z}, Z, v2f{a2.w, a2.w})));
+            L2[p] = __builtin_elementwise_fma(LX[p], LX[p], __builtin_elementwise_fma(LY[p], LY[p], LZ[p] * LZ[p]));
+        }
+        unsigned long long acc0 = 0ull, acc1 = 0ull;
+        if (wave < 2) batch3<kLut>(acc0, acc1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX);
+        else batch3<kLut + kCube>(acc0, acc1, Rs, Rz, Ry, Rx, L2, LZ, LY, LX);
+        total += acc0 + acc1;
+    }
+    A.out[gthread] = total;
+    if (A.stamps != nullptr && blockIdx.x == 0 && tid == 0) {
+        A.stamps[0] = __builtin_amdgcn_s_memtime() - t0;
+        A.stamps[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+}
+static double time_three(const char *name, Args A, int groups) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    int per_cu = 0;
+    CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, run3, kWaves * 64, 0));
+    Args W = A; W.batches = 20; W.stamps = nullptr;
+    hipLaunchKernelGGL(run3, dim3(groups), dim3(kWaves * 64), 0, 0, W);
+    CHECK(hipMemset(A.stamps, 0, 16));
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(run3, dim3(groups), dim3(kWaves * 64), 0, 0, A);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h[2]; CHECK(hipMemcpy(h, A.stamps, 16, hipMemcpyDeviceToHost));
+    const double ghz = h[1] ? (double)h[0] / ((double)h[1] * 10.0) : 0.0;
+    const double us_batch = ms * 1e3 / A.batches;
+    std::printf("%-28s %8.3f ms   %6.3f us per batch of a wave, %d workgroups resident per CU (%d waves per SIMD) = %.3f us per batch at the SIMD's rate of two waves   shader clock %.3f GHz\n",
+                name, ms, us_batch, per_cu, per_cu, us_batch * 2.0 / per_cu, ghz);
+    return us_batch;
+}
+
 template <int FORM>
 static double time_form(const char *name, Args A, int groups, std::vector<unsigned long long> *sums) {
     hipEvent_t e0, e1;
@@ -228,6 +306,8 @@ int main(int argc, char **argv) {
     time_form<5>("valu, no LUT read", A, groups, nullptr);
     time_form<6>("valu, no LUT read, 32-bit table", A, groups, nullptr);
     time_form<7>("valu, no LDS read at all", A, groups, nullptr);
+    std::printf("# three waves per SIMD (the product's block in 168 registers, 3 workgroups of 53 KB per CU; every wave runs %d batches):\n", batches);
+    time_three("valu, 3 waves per SIMD", A, prop.multiProcessorCount * 3);
     size_t differ = 0;
     for (size_t i = 0; i < s_valu.size(); i++) differ += s_valu[i] != s_mfma[i];
     std::printf("sums of the two forms differ in %zu of %zu lanes%s\n", differ, s_valu.size(), differ ? "  <-- NOT the same cells" : " (bitwise the same E: same cells, same sums)");
