@@ -55,8 +55,9 @@ Gso::Gso(Scorer &scorer, size_t n_swarms, size_t n_glowworms, const double *posi
     evals_ = arena_.upload(std::vector<unsigned long long>(1, (unsigned long long)total));
     std::vector<uint32_t> everybody(total);  // step 0 scores every glowworm (src/glowworm.rs:62)
     for (size_t i = 0; i < total; i++) everybody[i] = (uint32_t)i;
-    moved_list_ = arena_.upload(everybody);
-    moved_count_ = arena_.upload(std::vector<uint32_t>(1, (uint32_t)total));
+    moved_list_[0] = arena_.upload(everybody);
+    moved_list_[1] = arena_.upload(everybody);
+    moved_count_ = arena_.upload(std::vector<uint32_t>{(uint32_t)total, 0u});
 }
 
 Gso::~Gso() {
@@ -66,9 +67,8 @@ Gso::~Gso() {
 void Gso::step() {
     // Swarm::update_luciferin (src/swarm.rs:66-70): energies only for glowworms that moved
     // (or all of them at step 0); the luciferin arithmetic itself is folded into K2.
-    scorer_.energy_batch_device(n_swarms_ * n_glowworms_, poses_[cur_], pose_len_, active_, scoring_, nullptr, moved_list_,
-                                moved_count_);
-    hip_check(hipMemsetAsync(moved_count_, 0, sizeof(uint32_t), scorer_.stream()), "hipMemsetAsync(moved count)");
+    scorer_.energy_batch_device(n_swarms_ * n_glowworms_, poses_[cur_], pose_len_, active_, scoring_, nullptr, moved_list_[cur_],
+                                moved_count_ + cur_);
     GsoLaunch g;
     g.n_swarms = (int)n_swarms_;
     g.n_glowworms = (int)n_glowworms_;
@@ -88,8 +88,9 @@ void Gso::step() {
     g.step = step_;
     g.rng_key = rng_key_;
     g.evals = evals_;
-    g.moved_list = moved_list_;
-    g.moved_count = moved_count_;
+    g.moved_list = moved_list_[cur_ ^ 1];
+    g.moved_count = moved_count_ + (cur_ ^ 1);
+    g.zero_count = moved_count_ + cur_;   // (K1 of this step has read it; its next writer is K2 of the next step)
     hip_check(launch_gso_step(g, scorer_.stream()), "launch gso_movement_phase");
     cur_ ^= 1;
     steps_done_++;

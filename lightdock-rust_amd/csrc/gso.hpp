@@ -53,7 +53,9 @@ class Gso {
     int32_t *n_neighbors_ = nullptr, *target_ = nullptr;
     uint32_t *step_ = nullptr, *rng_key_ = nullptr;
     unsigned long long *evals_ = nullptr;
-    uint32_t *moved_list_ = nullptr, *moved_count_ = nullptr;  // K2 -> next K1: the glowworms to score, compacted
+    // K2 -> next K1: the glowworms to score, compacted.  Two lists and two counts, alternating like the pose buffers: K1 of a step reads
+    // list / count [cur_], K2 of the same step fills [cur_ ^ 1] and zeroes count [cur_] for its next filling -- no memset launch per step
+    uint32_t *moved_list_[2] = {nullptr, nullptr}, *moved_count_ = nullptr;
     hipGraphExec_t graph_exec_ = nullptr;  // two captured steps (even + odd pose buffer)
     int graph_cur_ = 0;
     uint64_t graph_generation_ = 0;  // scorer workspace generation the graph was captured against

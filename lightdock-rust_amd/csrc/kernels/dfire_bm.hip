@@ -1563,7 +1563,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
 }
 
 // ---------------------------------------------------------------------------------------------
-// dfire_bm_gather: two lanes = row of the pass: the pose's (ligand tile, row) sums -- integers, filled by the pair kernel's
+// dfire_bm_gather: eight lanes = row of the pass: the pose's (ligand tile, row) sums -- integers, filled by the pair kernel's
 // atomics, each below 2^61 -- added as f64 in a fixed order (a pose's total can pass 63 bits for an extreme table), plus the
 // exact path's sum.  A counting launch (count_mode) sums ones.
 // ---------------------------------------------------------------------------------------------
@@ -1571,24 +1571,28 @@ __global__ __launch_bounds__(256) void dfire_bm_gather(const BmLaunch launch_arg
     BmArgs *T = LD_BM_ARGS;
     const int n_lt = T->m.lig.n_tiles;
     const size_t n_rows = bm_rows(T);
-    // a wave = 32 rows x 2: lane l and lane l + 32 share row l, each every other ligand tile; the sums lie [ligand tile][row], so a
-    // load's 32 lanes read 32 consecutive words.  The sums are integers, their f64 images added in a fixed order.
-    const int lane = (int)threadIdx.x & 63, half = lane >> 5;
-    const size_t rows_per_trip = (size_t)gridDim.x * 128;
-    for (size_t first = (size_t)blockIdx.x * 128; first < n_rows; first += rows_per_trip) {   // (whole waves stay together for the shuffle)
-        const size_t row = first + (threadIdx.x >> 6) * 32 + (size_t)(lane & 31);
+    // eight lanes per row, each every eighth ligand tile (a small launch -- one swarm -- is all latency: few dependent loads a lane);
+    // the sums lie [ligand tile][row]: a load's 64 lanes read 8 tiles x 8 consecutive rows, eight 64-byte pieces.  The sums are
+    // integers, their f64 images added over the eight lanes in a fixed tree.
+    const int sub = (int)threadIdx.x & 7;
+    const size_t rows_per_trip = (size_t)gridDim.x * 32;
+    for (size_t first = (size_t)blockIdx.x * 32; first < n_rows; first += rows_per_trip) {   // (whole waves stay together for the shuffles)
+        const size_t row = first + threadIdx.x / 8;
         const bool valid = row < n_rows;
         const long long pp = valid ? bm_pose_of(T, row) : -1;
         double units = 0.0;
         uint32_t tested = 0;
         if (pp >= 0)
-            for (int lt = half; lt < n_lt; lt += 2) {
+            for (int lt = sub; lt < n_lt; lt += 8) {
                 units += (double)T->tile_sum[(size_t)lt * T->cap + row];   // [ligand tile][row of the pass]
                 if (T->count_mode && T->tile_tested) tested += T->tile_tested[row * (size_t)n_lt + lt];
             }
-        units += __shfl_xor(units, 32, 64);
-        tested += (uint32_t)__shfl_xor((int)tested, 32, 64);
-        if (pp < 0 || half != 0) continue;
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+            units += __shfl_xor(units, off, 64);
+            tested += (uint32_t)__shfl_xor((int)tested, off, 64);
+        }
+        if (pp < 0 || sub != 0) continue;
         const size_t pose = (size_t)pp;
         units += (double)T->exact_fix[row];
         if (T->count_mode) {   // (pair counts stay far below 2^53: exact)
@@ -1667,7 +1671,7 @@ hipError_t launch_bm_pairs(const BmLaunch &t, hipStream_t stream) {
 
 hipError_t launch_bm_gather(const BmLaunch &t, hipStream_t stream) {
     if (t.n_poses == 0) return hipSuccess;
-    hipLaunchKernelGGL(dfire_bm_gather, dim3((unsigned)std::min<size_t>((t.n_poses + 127) / 128, 8192)), dim3(256), 0, stream, t);   // 2 lanes per row
+    hipLaunchKernelGGL(dfire_bm_gather, dim3((unsigned)std::min<size_t>((t.n_poses + 31) / 32, 8192)), dim3(256), 0, stream, t);   // 8 lanes per row
     return hipGetLastError();
 }
 

@@ -158,6 +158,7 @@ __device__ __forceinline__ void gso_move(const GsoLaunch &G, size_t base, int i,
 // One thread per glowworm: what a launch that fills the chip with glowworms runs (a thread walks its swarm alone).
 __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && G.zero_count != nullptr) *G.zero_count = 0u;
     const int N = G.n_glowworms;
     double *sx = sh, *sy = sh + N, *sz = sh + 2 * N, *sl = sh + 3 * N;
     const int swarm = blockIdx.x / G.parts;
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(1024) void gso_movement_phase(const GsoLaunch G) {
 // 1.396 ms.  So: this one up to 16 384 glowworms, the other beyond (round 4; round 5: gso_step_is_phased).
 __global__ __launch_bounds__(1024) void gso_movement_phased(const GsoLaunch G) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && G.zero_count != nullptr) *G.zero_count = 0u;
     const int N = G.n_glowworms;
     double *sx = sh, *sy = sh + N, *sz = sh + 2 * N, *sl = sh + 3 * N;
     double *s_rnd = sh + 4 * N;   // per glowworm of this workgroup's share: its draw, its neighbour count, the neighbour it moves towards

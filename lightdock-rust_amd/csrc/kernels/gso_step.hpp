@@ -36,6 +36,7 @@ struct GsoLaunch {
     // (src/glowworm.rs:62).  *moved_count must be zero at launch.
     uint32_t *moved_list = nullptr;
     uint32_t *moved_count = nullptr;
+    uint32_t *zero_count = nullptr;   // the count this step's K1 read: set to zero for the step after next (instead of a memset launch per step)
 };
 
 constexpr size_t kGsoLdsLimit = 160 * 1024;   // a CU's LDS

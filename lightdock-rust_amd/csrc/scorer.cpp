@@ -827,14 +827,15 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     constexpr bool diag_rigid = false;
 #endif
     const TiledSoA &rec = tiled_rec_soa_, &lig = tiled_lig_soa_;
-    // Molecules that flex per pose (src/dfire.rs:288-320): the ANM form of the kernels, for up to kBmMaxModes modes a molecule and a
-    // receptor below 8192 atoms (the fixed-point scale's reach count is then the atom count whatever the deformation).
-    // LIGHTDOCK_BM_ANM=0: such complexes stay with the pose-major kernels (A/B, tests).
+    // Molecules that flex per pose (src/dfire.rs:288-320): the ANM form of the kernels, for up to kBmMaxModes modes a molecule (more:
+    // the pose-major kernel -- a stated contract, tests/test_gpu_parity.py::test_which_kernel_a_flexing_complex_gets).  The
+    // fixed-point scale's reach count allows for the deformation below (until round 6 a receptor of 8192 atoms or more was declined
+    // instead).  LIGHTDOCK_BM_ANM=0: such complexes stay with the pose-major kernels (A/B, tests).
     const bool anm = !diag_rigid && use_anm_ && (rec.num_anm > 0 || lig.num_anm > 0);
     if (anm) {
         const char *e = std::getenv("LIGHTDOCK_BM_ANM");
         if (e && std::atoi(e) == 0) return;
-        if (rec.num_anm > kBmMaxModes || lig.num_anm > kBmMaxModes || rec.n_real >= 8192) return;
+        if (rec.num_anm > kBmMaxModes || lig.num_anm > kBmMaxModes) return;
     }
     if (rec.n_tiles > 1024 || lig.n_tiles > 1024) return;  // an item of the exact path names its atoms in 16 bits each
     if (bm_cull_lds_bytes(rec.n_tiles) + 1024 > kBmLdsPerCu) return;  // the culling kernel keeps every receptor box in LDS: ~430 tiles at most
@@ -1048,7 +1049,11 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
         // the receptor atoms one ligand tile can reach -- inside 63 bits (dfire_bm_fix_scale)
         double tile_radius = 0.0;   // angstrom: the largest ligand tile's bounding sphere
         for (int t = 0; t < lig.n_tiles; t++) tile_radius = std::max(tile_radius, (double)bm_tile_radius_[t]);
-        const size_t reach_count = dfire_bm_reach_count(desc.receptor.coordinates, desc.receptor.n_atoms, 15.0 + tile_radius + 0.01);
+        // (flexing: in a pose that is not WILD no atom moves further than kBmWildUnits / kappa = 32 A from its place -- the atoms of a
+        // ligand tile stay within its radius + 32 A of its centre, a receptor atom within the cutoff of one of them rests within
+        // another 32 A: the ball grows by 64 A; a wild pose's sums are the exact path's, pair by pair)
+        const double flex_reach = anm ? 2.0 * (double)kBmWildUnits / kBmKappa : 0.0;
+        const size_t reach_count = dfire_bm_reach_count(desc.receptor.coordinates, desc.receptor.n_atoms, 15.0 + tile_radius + 0.01 + flex_reach);
         M.fix_scale = dfire_bm_fix_scale(table_vmax, reach_count, nullptr);
         if (!(M.fix_scale > 0.0)) return;
         std::vector<long long> rows((size_t)kBmTypes * kBmTypes * kBmRowSlots, 0), ones(rows.size(), 0);

@@ -1209,6 +1209,38 @@ def test_receptor_larger_than_one_ballot(pkg, orc, table, tmp_path, n_rec, box):
     assert bm_err(ap.energy_batch(poses), want) < REL_TOL
 
 
+def test_which_kernel_a_flexing_complex_gets(pkg, orc, table, tmp_path):
+    """The fallbacks of the block-major path's ANM form as a stated contract (VERDICT r05 item 5 ii; lightdock-rust_amd/csrc/scorer.cpp,
+    build_bm): up to ten modes a molecule run `dfire_bm_pairs` -- since round 6 also with a receptor of 8192 atoms or more (the
+    fixed-point scale then allows for the atoms a flexed ligand tile can reach) --, an eleventh mode sends the complex to the
+    pose-major `dfire_packed_pairs`; both give the oracle's energies and in-cutoff pair counts (src/dfire.rs:288-320)."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(77)
+    rec, lig = str(tmp_path / "flex_rec.pdb"), str(tmp_path / "flex_lig.pdb")
+    _random_protein_pdb(rec, 9000, 3, 38.0)
+    _random_protein_pdb(lig, 140, 4, 6.0)
+    dev = torch.device("cuda:0")
+    for n_rec_modes, n_lig_modes, want_kernel in ((3, 10, "dfire_bm_pairs"), (11, 2, "dfire_packed_pairs"), (0, 11, "dfire_packed_pairs")):
+        kw = dict(potential=table, use_anm=True, rec_num_anm=n_rec_modes, lig_num_anm=n_lig_modes,
+                  rec_nmodes=rng.normal(0.0, 0.02, size=n_rec_modes * 9000 * 3) if n_rec_modes else None,
+                  lig_nmodes=rng.normal(0.0, 0.1, size=n_lig_modes * 140 * 3) if n_lig_modes else None)
+        hip = pkg.Scorer.from_pdb("dfire", rec, lig, **kw)
+        cpu = orc.Scorer("dfire", rec, lig, **kw)
+        assert hip.kernel_info()["pair_kernel_name"] == want_kernel, (n_rec_modes, n_lig_modes)
+        poses = pkg.synth.swarm(16, seed=21)
+        poses[:, :3] *= 0.9
+        poses = np.ascontiguousarray(np.concatenate([poses[:, :7], rng.normal(0.0, 3.0, size=(16, n_rec_modes + n_lig_modes))], axis=1))
+        want = [cpu.energy_ex_row(p) for p in poses]
+        d_poses = torch.from_numpy(poses).to(dev)
+        d_out = torch.zeros(len(poses), dtype=torch.float64, device=dev)
+        d_cnt = torch.zeros(len(poses), dtype=torch.int32, device=dev)
+        hip.energy_batch_device(len(poses), d_poses.data_ptr(), poses.shape[1], d_out.data_ptr(), None, d_cnt.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(d_cnt.cpu().numpy().astype(np.int64), np.array([w[1][5] for w in want]).astype(np.int64))
+        err = bm_err if want_kernel == "dfire_bm_pairs" else rel_err
+        assert err(d_out.cpu().numpy(), np.array([w[0] for w in want])) < REL_TOL
+
+
 def test_bench_plain_command_runs_n_ranks(pkg):
     """`python bench.py --gpus 2` (no torchrun): bench.py starts the two ranks itself; on this 1-GPU box both are pinned to
     device 0 (LD_BENCH_FORCE_DEVICE) and the timing collectives go over gloo.  One JSON line, n_gpus 2, whole-job value."""
