@@ -19,7 +19,7 @@
 // The LD_BM_DIAG_* blocks below are TIMING EXPERIMENTS (wrong sums by construction).  They compile only in a diagnostic build
 // (-DLD_DIAG_BUILD, which tools/build_variant.sh passes): the shipped library cannot be built with one of them by accident, and
 // tests/test_host_cpu.py checks that it carries no diagnostic switch.
-#if !defined(LD_DIAG_BUILD) && (defined(LD_BM_DIAG_ANM_COST) || defined(LD_BM_DIAG_ANM_LDS) || defined(LD_BM_DIAG_FIRST) || defined(LD_BM_DIAG_NO_ATOMIC) || defined(LD_BM_DIAG_NO_DMA) || defined(LD_BM_DIAG_NO_PAIRS) || defined(LD_BM_DIAG_NO_PARTIAL) || defined(LD_BM_DIAG_NO_POSE) || defined(LD_BM_DIAG_NO_TRACKED) || defined(LD_BM_DIAG_ROW_OF_LANE) || defined(LD_BM_DIAG_WAIT))
+#if !defined(LD_DIAG_BUILD) && (defined(LD_BM_DIAG_ANM_COST) || defined(LD_BM_DIAG_ANM_LDS) || defined(LD_BM_DIAG_FIRST) || defined(LD_BM_DIAG_NO_ATOMIC) || defined(LD_BM_DIAG_NO_DMA) || defined(LD_BM_DIAG_NO_EXACT) || defined(LD_BM_DIAG_NO_EXACT_ATOMIC) || defined(LD_BM_DIAG_NO_PAIRS) || defined(LD_BM_DIAG_NO_PARTIAL) || defined(LD_BM_DIAG_NO_POSE) || defined(LD_BM_DIAG_NO_TRACKED) || defined(LD_BM_DIAG_ROW_OF_LANE) || defined(LD_BM_DIAG_WAIT))
 #error "LD_BM_DIAG_* needs -DLD_DIAG_BUILD (tools/build_variant.sh)"
 #endif
 
@@ -156,18 +156,22 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
         if (T->exact_pairs) T->exact_pairs[listed] = 0;
         if (T->amp != nullptr) {   // the pose's mode amplitudes as the pair kernel loads them (f32: their rounding is part of eps), and whether it is WILD
             float *am = T->amp + listed * kBmAmpFloats;
-            float reach_rec = 0.f, reach_lig = 0.f;
+            float n2_rec = 0.f, n2_lig = 0.f;   // |amplitudes|^2 of either molecule (the f32 values the kernels multiply with)
 #pragma unroll
             for (int k = 0; k < kBmMaxModes; k++) {
                 const float ar = k < T->m.anm_rec ? (float)row[7 + k] : 0.f, al = k < T->m.anm_lig ? (float)row[7 + T->m.anm_rec + k] : 0.f;
                 am[k] = ar;
                 am[kBmMaxModes + k] = al;
-                reach_rec = __builtin_fmaf(fabsf(ar), T->m.rec_mode_reach[k], reach_rec);
-                reach_lig = __builtin_fmaf(fabsf(al), T->m.lig_mode_reach[k], reach_lig);
+                n2_rec = __builtin_fmaf(ar, ar, n2_rec);
+                n2_lig = __builtin_fmaf(al, al, n2_lig);
             }
-            // (NaN amplitudes: not below the bound either -> wild -> the exact path, where the reference's arithmetic decides)
-            am[20] = reach_rec <= kBmWildUnits && reach_lig <= kBmWildUnits ? 0.f : 1.f;
-            am[21] = am[22] = am[23] = 0.f;
+            // Cauchy-Schwarz: no coordinate of an atom, and no partial sum of its ten terms, moves further than |a|_2 x the largest 2-norm
+            // of an atom's mode components of that coordinate (BmModel); 1.0001: the roundings of this sum, of the root and of the ten
+            // terms.  (NaN or infinite amplitudes: not below the bound -> wild -> the exact path, where the reference's arithmetic decides)
+            const float na_rec = sqrtf(n2_rec) * 1.0001f, na_lig = sqrtf(n2_lig) * 1.0001f;
+            am[20] = na_rec * T->m.rec_mode_norm <= kBmWildUnits && na_lig * T->m.lig_mode_norm <= kBmWildUnits ? 0.f : 1.f;
+            am[21] = na_lig * T->m.lig_mode_norm_vec;   // how far a ligand atom can move (the culling kernel's sphere test)
+            am[22] = am[23] = 0.f;
             double *ax = T->amp_exact + listed * (2 * kBmMaxModes);
 #pragma unroll
             for (int k = 0; k < kBmMaxModes; k++) {
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     float4 my_a0 = float4{0.f, 0.f, 0.f, 0.f}, my_a1 = my_a0, my_a2 = my_a0;
     if (lane < group_poses && listed0 + lane < rows) my_pose = bm_pose_of(T, listed0 + lane);
     float my_amp[kBmMaxModes];   // ANM: the pose's ligand amplitudes (lane g: pose g)
-    float my_wild = 0.f;
+    float my_wild = 0.f, my_flex = 0.f;
 #pragma unroll
     for (int k = 0; k < kBmMaxModes; k++) my_amp[k] = 0.f;
     if (my_pose >= 0) {
@@ -368,6 +372,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
 #pragma unroll
             for (int k = 0; k < kBmMaxModes; k++) my_amp[k] = am[k];
             my_wild = am[kBmMaxModes];   // (the row's float 20)
+            my_flex = am[kBmMaxModes + 1];
         }
     }
     auto pose_lane = [](float v, int g) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), g)); };
@@ -454,9 +459,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
             tiles_g = T->anm_tile + (listed0 + (size_t)g) * n_rt;
             subs_g = reinterpret_cast<const BmCullBox *>(T->anm_sub) + (listed0 + (size_t)g) * n_rt * 8;
             my_tile = lane < n_rt ? tiles_g[lane] : no_tile;
-#pragma unroll
-            for (int k = 0; k < kBmMaxModes; k++) flex_reach = __builtin_fmaf(fabsf(pose_lane(my_amp[k], g)), T->m.lig_mode_reach[k], flex_reach);
-            flex_reach *= 1.0001f;
+            flex_reach = pose_lane(my_flex, g);   // (dfire_bm_pose: |amplitudes|_2 x the largest mode vector norm of a ligand atom)
         }
         auto tile_at = [&](int i) { return ANM ? tiles_g[i] : s_tile[i]; };
         auto sub_at = [&](int i) { return ANM ? subs_g[i] : s_sub[i]; };   // subtile i of the receptor as {lo, -hi} pairs
@@ -781,6 +784,9 @@ __device__ __forceinline__ unsigned long long bm_pair_item(uint32_t row, int la,
 }
 
 __device__ __forceinline__ void bm_exact_pairs(BmArgs *T, unsigned long long *queue, uint32_t n_pairs, int lane) {
+#ifdef LD_BM_DIAG_NO_EXACT   // (diagnostic builds: timing only, wrong sums -- the kernel without its exact path)
+    return;
+#endif
     // the wave reads back what it pushed itself: its stores are complete (through the write-through L1, in the XCD's L2), and
     // the loads below go past the L1.  (An agent-scope release here writes the whole L2 back, on every drain of every wave:
     // the launch took twice as long.)
@@ -893,7 +899,11 @@ __device__ __forceinline__ void bm_exact_pairs(BmArgs *T, unsigned long long *qu
             if (!inside[u]) continue;
             // a counting launch sums ones: the pair counts if it is within the cutoff
             const long long fix = T->count_mode ? 1ll : __double2ll_rn(value[u] * T->m.fix_scale);
+#ifndef LD_BM_DIAG_NO_EXACT_ATOMIC   // (diagnostic builds: timing only, wrong sums)
             if (fix != 0) atomicAdd(reinterpret_cast<unsigned long long *>(T->exact_fix + row[u]), (unsigned long long)fix);
+#else
+            asm volatile("" :: "v"(fix));
+#endif
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the list is read before it is written again

@@ -81,10 +81,16 @@ constexpr int kBmPassQuantum = 1024;         // poses per pass: a multiple of th
 constexpr int kBmOpsFloats = 36;             // BmModel::rec_ops: Rs[4][2], Rz[4][2], Ry[4][2], Rx[4][2], cx, cy, cz, 0
 constexpr int kBmMaxModes = 10;              // normal modes per molecule the ANM form of the path takes (the reference's examples: 10 + 10, src/dfire.rs:288-320)
 constexpr int kBmModeFloats = 8 * 3 * kBmMaxModes;   // a subtile's modes as a batch reads them: ((atom pair p * 3 + coordinate) * kBmMaxModes + mode) * 2 + atom of the pair
-constexpr int kBmAmpFloats = 24;             // a row's amplitudes as the pair kernel loads them: receptor modes 0..9, ligand modes 10..19, [20] != 0: a WILD pose
+constexpr int kBmAmpFloats = 24;             // a row's amplitudes as the pair kernel loads them: receptor modes 0..9, ligand modes 10..19, [20] != 0: a WILD pose,
+                                             // [21]: how far the row's amplitudes can move a ligand atom (record units; the culling kernel's sphere test)
 constexpr int kBmAnmPartEntries = 1024;      // entries of a tile pair in one job of the ANM form (its LDS holds two subtiles' modes where the other keeps the entries' rows of the pass)
-constexpr float kBmWildUnits = 256.0f;       // a pose whose amplitudes could move an atom further than this (record units: 32 A) is WILD: every pair of its
-                                             // blocks goes to the exact path (the f32 arithmetic's error bound covers deformations up to here)
+constexpr float kBmWildUnits = 128.0f;       // a pose whose amplitudes could move a coordinate of an atom further than this (record units: 16 A) is WILD: every
+                                             // pair of its blocks goes to the exact path (the f32 arithmetic's error bound covers deformations up to here).
+                                             // The test is Cauchy-Schwarz per molecule: |sum_k a_k m_k| <= |a|_2 x max over atoms and coordinates of |m|_2
+                                             // (BmModel::rec_mode_norm) -- 14.1 A at most over the starting poses of the reference's ANM examples (1czy),
+                                             // 7.8 / 10.7 A for 2uuy.  (Until round 6: 256 units against sum_k |a_k| max |m_k|, 21.5 A for 2uuy; the bound on
+                                             // the distance arithmetic's operands, and with it the LUT's eps, is what W buys: 0.87 -> 0.49 cells for 2uuy,
+                                             // one flagged cell per bin step instead of three.)
 constexpr int kBmCubeRows = 64;              // table rows of a block: 8 ligand x 8 receptor atoms
 constexpr int kBmCubeBytes = kBmCubeRows * kBmRowBytes;
 constexpr int kBmTypes = 170;                // 169 DFIRE types + one all-zero type for padding atoms
@@ -151,7 +157,9 @@ struct BmModel {
     float rec_box_pad = 0.f;                    // record units: how far an f32-flexed receptor atom of a pose that is not wild can be from the exact one, per coordinate
     const double *rec_modes_exact = nullptr;    // f64 [atom (tile order)][kBmMaxModes][x y z]: what the exact path reads of an atom's modes, 240 contiguous bytes
     const double *lig_modes_exact = nullptr;    //   (src/dfire.rs:288-320; absent modes 0, never read)
-    float rec_mode_reach[kBmMaxModes] = {}, lig_mode_reach[kBmMaxModes] = {};   // kappa x the largest |mode vector| of an atom, per mode: sum |amplitude| x this bounds a pose's deformation
+    float rec_mode_norm = 0.f, lig_mode_norm = 0.f;   // kappa x max over atoms and coordinates of the 2-norm of the ten mode components (f32 values, rounded up):
+                                                      // |amplitudes|_2 x this bounds every coordinate's deformation and every partial sum of it (Cauchy-Schwarz)
+    float lig_mode_norm_vec = 0.f;                    // the same over an atom's thirty components: |amplitudes|_2 x this bounds how far a ligand atom moves
     // ligand
     TiledLigand lig;                            // f64, tile order (exact path, overflow tiles)
     const double *lig_exact = nullptr, *rec_exact = nullptr;   // [atom][4]: x, y, z (f64) and {table term, interface-flag slot}: what the exact path reads of an atom, in two loads

@@ -671,8 +671,9 @@ double dfire_bm_error_bound(double ubound, double lig_extent, bool anm) {
     const double span = std::sqrt(3.0 * 1100.0 * kBmCells);     // |du| + |dv| + |dw| <= sqrt(3) |d|, pairs within 1100 units of 4 d2
     // The ten roundings of the distance arithmetic: every operand and partial sum of such a pair is below 2^17
     // (|l - c| <= 16.6 A + a subtile's half extent < 45 A = 362 record units; the seed carries the LUT's offset, < 2^15).
-    // (flexing: r - c + d up to 128 + W, l - c up to that + the cutoff's 133 units -- squares below 2^19)
-    const double eps = 2.0 * e_d * span + 3.0 * e_d * e_d + 10.0 * half_ulp((anm ? 524288.0 : 131072.0) * 0.999);
+    // (flexing: r - c + d up to 128 + W, l - c up to that + the cutoff's 134 units: their squares bound every operand and partial sum)
+    const double top = anm ? std::max(131072.0, (128.0 + W + 134.0) * (128.0 + W + 134.0)) : 131072.0;
+    const double eps = 2.0 * e_d * span + 3.0 * e_d * e_d + 10.0 * half_ulp(top * 0.999);
     return 2.0 * eps;  // twice the bound, LUT cells
 }
 
@@ -947,7 +948,7 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
     if (anm) {   // the modes as the kernels read them: kappa x, f32 (BmModel)
         M.anm_rec = rec.num_anm;
         M.anm_lig = lig.num_anm;
-        auto tables = [&](const TiledSoA &m, std::vector<float> &by_subtile, std::vector<float> *by_atom, float *reach, const double **exact) {
+        auto tables = [&](const TiledSoA &m, std::vector<float> &by_subtile, std::vector<float> *by_atom, float *norm_coord, float *norm_atom, const double **exact) {
             const size_t pad = (size_t)m.n_tiles * 64;
             std::vector<double> per_atom(pad * 3 * (size_t)kBmMaxModes, 0.0);   // [atom][mode][x y z], the reference's numbers
             for (int k = 0; k < m.num_anm; k++)
@@ -956,27 +957,29 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
             *exact = arena_.upload(per_atom);
             by_subtile.assign(pad / 8 * (size_t)kBmModeFloats, 0.f);
             if (by_atom) by_atom->assign(pad * 32, 0.f);
-            for (int k = 0; k < kBmMaxModes; k++) reach[k] = 0.f;
-            for (int k = 0; k < m.num_anm; k++) {
-                double longest = 0.0;
-                for (size_t i = 0; i < pad; i++) {
-                    double n2 = 0.0;
+            // per atom: the 2-norm of the ten components of a coordinate, and of all thirty -- of the f32 values the kernels multiply with
+            std::vector<double> n2((size_t)pad * 3, 0.0);
+            for (int k = 0; k < m.num_anm; k++)
+                for (size_t i = 0; i < pad; i++)
                     for (int c = 0; c < 3; c++) {
                         const double v = m.hmodes[((size_t)k * 3 + c) * pad + i];
                         const float f = (float)(kBmKappa * v);
                         by_subtile[(i / 8) * (size_t)kBmModeFloats + ((((i % 8) / 2) * 3 + c) * (size_t)kBmMaxModes + k) * 2 + (i & 1)] = f;
                         if (by_atom) (*by_atom)[i * 32 + 3 * (size_t)k + c] = f;
-                        n2 += v * v;
+                        n2[i * 3 + c] += (double)f * (double)f;
                     }
-                    longest = std::max(longest, std::sqrt(n2));
-                }
-                // (not finite: every pose with a non-zero amplitude of this mode is wild; NaN stays NaN and fails the kernel's comparison)
-                reach[k] = std::nextafter((float)(kBmKappa * longest * 1.001), INFINITY);
+            double coord = 0.0, atom = 0.0;
+            for (size_t i = 0; i < pad; i++) {
+                for (int c = 0; c < 3; c++) coord = std::max(coord, n2[i * 3 + c]);
+                atom = std::max(atom, n2[i * 3] + n2[i * 3 + 1] + n2[i * 3 + 2]);
             }
+            // (not finite: every pose with a non-zero amplitude is wild; NaN stays NaN and fails the kernel's comparison)
+            *norm_coord = std::nextafter((float)(std::sqrt(coord) * 1.000001), INFINITY);
+            if (norm_atom) *norm_atom = std::nextafter((float)(std::sqrt(atom) * 1.000001), INFINITY);
         };
         std::vector<float> rsub, lsub, latom, ratom;
-        tables(rec, rsub, &ratom, M.rec_mode_reach, &M.rec_modes_exact);
-        tables(lig, lsub, &latom, M.lig_mode_reach, &M.lig_modes_exact);
+        tables(rec, rsub, &ratom, &M.rec_mode_norm, nullptr, &M.rec_modes_exact);
+        tables(lig, lsub, &latom, &M.lig_mode_norm, &M.lig_mode_norm_vec, &M.lig_modes_exact);
         M.rec_modes_f32 = arena_.upload(rsub);
         M.lig_modes_f32 = arena_.upload(lsub);
         M.lig_modes_atom = arena_.upload(latom);
@@ -1049,10 +1052,11 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
         // the receptor atoms one ligand tile can reach -- inside 63 bits (dfire_bm_fix_scale)
         double tile_radius = 0.0;   // angstrom: the largest ligand tile's bounding sphere
         for (int t = 0; t < lig.n_tiles; t++) tile_radius = std::max(tile_radius, (double)bm_tile_radius_[t]);
-        // (flexing: in a pose that is not WILD no atom moves further than kBmWildUnits / kappa = 32 A from its place -- the atoms of a
-        // ligand tile stay within its radius + 32 A of its centre, a receptor atom within the cutoff of one of them rests within
-        // another 32 A: the ball grows by 64 A; a wild pose's sums are the exact path's, pair by pair)
-        const double flex_reach = anm ? 2.0 * (double)kBmWildUnits / kBmKappa : 0.0;
+        // (flexing: in a pose that is not WILD no coordinate of an atom moves further than kBmWildUnits / kappa = 16 A, the atom no
+        // further than sqrt(3) x that = 27.7 A from its place -- the atoms of a ligand tile stay within its radius + 27.7 A of its
+        // centre, a receptor atom within the cutoff of one of them rests within another 27.7 A: the ball grows by 55.4 A; a wild
+        // pose's sums are the exact path's, pair by pair)
+        const double flex_reach = anm ? 2.0 * std::sqrt(3.0) * (double)kBmWildUnits / kBmKappa : 0.0;   // (W bounds a coordinate: sqrt(3) W the atom)
         const size_t reach_count = dfire_bm_reach_count(desc.receptor.coordinates, desc.receptor.n_atoms, 15.0 + tile_radius + 0.01 + flex_reach);
         M.fix_scale = dfire_bm_fix_scale(table_vmax, reach_count, nullptr);
         if (!(M.fix_scale > 0.0)) return;

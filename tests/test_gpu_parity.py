@@ -1303,7 +1303,8 @@ def test_block_major_frame_edges_and_absurd_poses(pkg, scorers, orc, name):
 @pytest.mark.gpu
 def test_block_major_anm_form_and_wild_amplitudes(pkg, scorers, orc):
     """DFIRE with normal modes (src/dfire.rs:288-320) runs the block-major path's ANM form: both molecules flex per pose
-    inside the batch.  Its f32 bounds cover deformations up to 32 A; a pose whose amplitudes could exceed that -- or are not
+    inside the batch.  Its f32 bounds cover deformations up to 16 A per coordinate (round 6; 32 A before); a pose whose amplitudes
+    could exceed that (|amplitudes|_2 x the largest 2-norm of an atom's mode components, Cauchy-Schwarz) -- or are not
     finite -- is WILD: every block of it goes to the exact path.  Ordinary, large, absurd, NaN and infinite amplitudes must
     give the oracle's energies and in-cutoff pair counts, and leave their neighbours bit for bit what they are alone."""
     torch = pytest.importorskip("torch")
