@@ -118,8 +118,10 @@ __global__ __launch_bounds__(256) void dfire_bm_pose(const BmLaunch launch_argum
     }
     {   // the (ligand tile, row) sums of the pass, [ligand tile][cap rows]: per ligand tile the first `rows` words, cleared by consecutive
         // threads
-        const size_t sums = rows * (size_t)T->m.lig.n_tiles;
-        for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < sums; k += (size_t)gridDim.x * 256) T->tile_sum[(k / rows) * T->cap + k % rows] = 0;
+        // (thread = row, a loop over the ligand tiles: consecutive threads clear consecutive words, and no division per word)
+        const int n_lt = T->m.lig.n_tiles;
+        for (size_t r = (size_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (size_t)gridDim.x * 256)
+            for (int lt = 0; lt < n_lt; lt++) T->tile_sum[(size_t)lt * T->cap + r] = 0;
     }
     for (size_t listed = (size_t)blockIdx.x * 256 + threadIdx.x; listed < rows; listed += (size_t)gridDim.x * 256) {
         const long long p = bm_pose_of(T, listed);
