@@ -163,12 +163,12 @@ KERNEL_SOURCES = ("lightdock-rust_amd/csrc/kernels/dfire_bm.hip", "lightdock-rus
                   "lightdock-rust_amd/csrc/kernels/dfire_packed.hpp", "lightdock-rust_amd/csrc/kernels/dfire_tiled.hip",
                   "lightdock-rust_amd/csrc/kernels/dfire_tiled.hpp", "lightdock-rust_amd/csrc/kernels/pose_energy.hip",
                   "lightdock-rust_amd/csrc/kernels/pose_energy.hpp", "lightdock-rust_amd/csrc/kernels/gso_step.hip",
-                  "lightdock-rust_amd/csrc/scorer.cpp")
+                  "lightdock-rust_amd/csrc/scorer.cpp", "lightdock-rust_amd/csrc/host/spatial_order.cpp")
 
 
 def kernel_source_hash():
     """What ties a committed counter profile to the build it was taken from: a hash of the kernel sources and of
-    scorer.cpp (launch shapes, LUTs, layouts), comments and whitespace left out.  tools/update_traffic.py stamps it on every entry of profiles/traffic.json."""
+    scorer.cpp (launch shapes, LUTs, layouts) and spatial_order.cpp (the atom order: how many blocks a pose has), comments and whitespace left out.  tools/update_traffic.py stamps it on every entry of profiles/traffic.json."""
     import hashlib
     import re
     h = hashlib.sha256()
@@ -261,6 +261,10 @@ def main():
     ap.add_argument("--zero-last-bin", action="store_true",
                     help="DFIRE: zero bin 19 (14..15 A) of the synthetic table, as DFIRE's reference state does by construction; "
                          "NOT the headline configuration, reported separately in DESIGN.md")
+    ap.add_argument("--zero-bead-rows", action="store_true",
+                    help="DFIRE: zero the rows of receptor type 167 (lightdock's membrane beads, src/dfire.rs:40,77) in the synthetic table -- "
+                         "what a DCparams without statistics for the beads would hold; their subtiles are then listed within the interface "
+                         "distance only (VERDICT r05 item 8).  NOT the headline configuration, reported separately in DESIGN.md")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--no-stats", action="store_true",
                     help="skip the counting launch (in-cutoff pairs, blocks) in front of the timed region: for profiler runs, whose per-kernel "
@@ -300,6 +304,9 @@ def main():
     if table is not None and args.zero_last_bin:
         table = table.copy()
         table.reshape(169, 169, 20)[:, :, 19] = 0.0
+    if table is not None and args.zero_bead_rows:
+        table = table.copy()
+        table.reshape(169, 169, 20)[167, :, :] = 0.0
     kw = dict(case["kw"])
     if table is not None:
         kw["potential"] = table
@@ -365,7 +372,7 @@ def main():
         total_evals = batch * args.steps * world
         scaling = "weak"
         shape = "%s %s pose-energy batch, %d poses/GPU/step, %d x %d atoms%s" % (
-            system, case["method"].upper(), batch, n_rec, n_lig, ((", synthetic DCparams" + (" with bin 19 zeroed" if args.zero_last_bin else "")) if table is not None else "") + (", 10 + 10 ANM modes" if case["kw"].get("use_anm") else ""))
+            system, case["method"].upper(), batch, n_rec, n_lig, ((", synthetic DCparams" + (" with bin 19 zeroed" if args.zero_last_bin else "") + (" with the membrane beads' rows (type 167) zeroed" if args.zero_bead_rows else "")) if table is not None else "") + (", 10 + 10 ANM modes" if case["kw"].get("use_anm") else ""))
         extra = {"poses_per_step_per_gpu": batch, "nominal_pair_tests_per_pose": info["pair_tests_per_pose"],
                  "mean_pairs_in_cutoff": float(p_cut.mean()), "mean_8x8_blocks_evaluated": blocks}
         units_per_launch = batch
@@ -420,7 +427,7 @@ def main():
         algo_bytes_launch = float((info["stream_bytes_per_pose"] + 8 * mean_cut) * evals_per_launch)
         shape = "%s DFIRE GSO, %d swarms x 200 glowworms%s, %d x %d atoms, synthetic DCparams%s" % (
             system, swarms_total, " sharded over the ranks" if scaling == "strong" else " per GPU", n_rec, n_lig,
-            " with bin 19 zeroed" if args.zero_last_bin else "")
+            (" with bin 19 zeroed" if args.zero_last_bin else "") + (" with the membrane beads' rows (type 167) zeroed" if args.zero_bead_rows else ""))
         extra = {"swarms_this_rank": len(mine), "glowworms": 200, "mean_pairs_in_cutoff_of_start_poses": mean_cut,
                  "gso_steps_per_s": args.steps / elapsed,
                  "k1_k2_split": {"pair_kernel_ms_per_step": kern_ms / max(launches, 1), "whole_step_ms": 1e3 * dt10 / 10,
@@ -434,7 +441,7 @@ def main():
     if rank == 0:
         kern_s = kern_ms / 1e3 / max(launches, 1)
         achieved = algo_bytes_launch / kern_s / 1e9
-        flags = "" if not args.zero_last_bin else ":zero-last-bin"
+        flags = ("" if not args.zero_last_bin else ":zero-last-bin") + ("" if not args.zero_bead_rows else ":zero-bead-rows")
         prof, stale = profile_entry(args.workload, int(units_per_launch) if kind == "k1" else len(mine), info["pair_kernel_name"], flags)
         # The vector units issue most of what these kernels run (packed f32, f64, conversions, integer max) at one wave
         # instruction per ~4.5 cycles per SIMD (profiles/r02_valu_issue_rates.txt); only plain f32 add / mul / fma and

@@ -212,6 +212,13 @@ int ld_scorer_energy_batch_device(ld_scorer *s, size_t n, const double *d_poses,
  * LD_ERR_UNSUPPORTED for scorers that run the all-pairs kernel. */
 int ld_scorer_last_block_counts(ld_scorer *s, size_t n, uint32_t *blocks_out_host);
 
+/* Diagnostics of the block-major DFIRE path: the number of receptor subtiles (8 atoms of the tile order) whose atoms' rows of the
+ * potential -- atoma * 169 * 20 + atomb * 20 + bin, src/dfire.rs:338, all 20 bins and the read past the row at r = 15.0 -- are 0.0
+ * against every ligand type of the complex (membrane beads, if the DCparams at hand has zero rows for them).  Such a subtile adds
+ * nothing to any sum: the culling lists its blocks within the interface distance only (r <= 2.45 A, src/dfire.rs:339; never, when
+ * neither it nor the ligand holds a restraint atom or a bead).  0 for a table without such rows and for the other kernels. */
+int ld_scorer_bm_quiet_subtiles(const ld_scorer *s, uint32_t *count_out);
+
 /* Per-launch facts for the measurement harness. */
 typedef struct ld_kernel_info {
     const char *pair_kernel_name; /* symbol of the dominant (pair loop) kernel */

@@ -112,6 +112,7 @@ def load_library():
     lib.ld_scorer_energy_batch_device.argtypes = [vp, sz, vp, sz, vp, vp, vp]
     lib.ld_scorer_kernel_info.argtypes = [vp, C.POINTER(_KernelInfo)]
     lib.ld_scorer_last_block_counts.argtypes = [vp, sz, vp]
+    lib.ld_scorer_bm_quiet_subtiles.argtypes = [vp, vp]
     lib.ld_scorer_enable_timing.argtypes = [vp, C.c_int]
     lib.ld_scorer_pair_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.ld_gso_create.restype = vp
@@ -425,6 +426,12 @@ class Scorer:
         out = np.zeros(n, dtype=np.uint32)
         _check(self.lib.ld_scorer_last_block_counts(self._h, n, _ptr(out)))
         return out
+
+    def bm_quiet_subtiles(self):
+        """Receptor subtiles whose atoms' rows of the potential are zero against every ligand type (block-major DFIRE path)."""
+        n = C.c_uint32()
+        _check(self.lib.ld_scorer_bm_quiet_subtiles(self._h, C.byref(n)))
+        return n.value
 
     def kernel_info(self):
         info = _KernelInfo()

@@ -296,6 +296,13 @@ int ld_scorer_last_block_counts(ld_scorer *s, size_t n, uint32_t *blocks_out_hos
     });
 }
 
+int ld_scorer_bm_quiet_subtiles(const ld_scorer *s, uint32_t *count_out) {
+    return guarded([&] {
+        if (!s || !count_out) throw ld::Error(LD_ERR_INVALID, "null argument");
+        *count_out = s->impl.bm_quiet_subtiles();
+    });
+}
+
 int ld_scorer_kernel_info(const ld_scorer *s, ld_kernel_info *out) {
     return guarded([&] {
         if (!s || !out) throw ld::Error(LD_ERR_INVALID, "null argument");

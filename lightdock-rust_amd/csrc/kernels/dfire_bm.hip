@@ -38,11 +38,12 @@ typedef const __attribute__((address_space(4))) BmLaunch BmArgs;
 #endif
 constexpr int kBmCullPoses = LD_BM_CULL_POSES;   // poses a wave of dfire_bm_cull walks with its ligand tile
 constexpr int kBmCullQueues = kBmCullQueueWords;   // (1k4c: 8 queues 695 us, 16 581, 32 388, 64 320, 128 ~310, 256 296, 512 316; static 337)   // counters the waves of dfire_bm_cull draw their items from
-constexpr float kBmBoxCut = 14400.0f * 1.00005f;  // (8 * 15 A)^2 in record units, padded for the rounding of the box test
+constexpr float kBmBoxCut = kBmBoxCutUnits2;  // (8 * 15 A)^2 in record units, padded for the rounding of the box test
 // A receptor subtile's box as the culling kernel keeps it in LDS: per axis the pair {lo, -hi}.  With the ligand subtile's box as
 // {-hi, lo} the two differences of an axis' gap -- lo_r - hi_l and lo_l - hi_r, the values axis_gap forms -- are ONE packed add.
 struct BmCullBox {
-    v2f x, y, z, unused;
+    v2f x, y, z;
+    float cut, unused;   // the subtile's reach, squared (kBmBoxCut unless its atoms' rows of the potential are zero: scorer.cpp, build_bm)
 };
 static_assert(sizeof(BmCullBox) == sizeof(TiledBox), "same room in LDS");
 __device__ __forceinline__ float bm_cull_gap2(v2f lx, v2f ly, v2f lz, const BmCullBox &r) {   // = box_gap2, bit for bit
@@ -242,9 +243,10 @@ __global__ __launch_bounds__(256) void dfire_bm_rec_boxes(const BmLaunch launch_
                     hi[c] = fmaxf(hi[c], fmaxf(f.x, second));
                 }
             }
+            const float sub_cut = ((const_f32 *)(uintptr_t)(T->m.rec_sub + (size_t)RT * 8 + (size_t)sb))[3];   // (TiledBox::pad0: the static image's reach)
             if (have && wild == 0.f)
                 reinterpret_cast<BmCullBox *>(T->anm_sub)[(row * (size_t)n_rt + RT) * 8 + sb] =
-                    BmCullBox{v2f{lo[0] - pad, -(hi[0] + pad)}, v2f{lo[1] - pad, -(hi[1] + pad)}, v2f{lo[2] - pad, -(hi[2] + pad)}, v2f{0.f, 0.f}};
+                    BmCullBox{v2f{lo[0] - pad, -(hi[0] + pad)}, v2f{lo[1] - pad, -(hi[1] + pad)}, v2f{lo[2] - pad, -(hi[2] + pad)}, sub_cut, 0.f};
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 tlo[c] = fminf(tlo[c], lo[c]);
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void dfire_bm_rec_boxes(const BmLaunch launch_
             }
         }
         if (have && wild == 0.f)
-            T->anm_tile[row * (size_t)n_rt + RT] = TiledBox{tlo[0] - pad, tlo[1] - pad, tlo[2] - pad, 0.f, thi[0] + pad, thi[1] + pad, thi[2] + pad, 0.f};
+            T->anm_tile[row * (size_t)n_rt + RT] = TiledBox{tlo[0] - pad, tlo[1] - pad, tlo[2] - pad, ((const_f32 *)(uintptr_t)(T->m.rec_tile + RT))[3], thi[0] + pad, thi[1] + pad, thi[2] + pad, 0.f};
     }
 }
 
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         for (int k = threadIdx.x; k < n_rt * 8; k += kBmCullWaves * 64) {
             const uint4 lo = src_sub[2 * k], hi = src_sub[2 * k + 1];   // a TiledBox: lo x y z ., hi x y z .
             reinterpret_cast<uint4 *>(s_sub)[2 * k] = uint4{lo.x, hi.x ^ 0x80000000u, lo.y, hi.y ^ 0x80000000u};
-            reinterpret_cast<uint4 *>(s_sub)[2 * k + 1] = uint4{lo.z, hi.z ^ 0x80000000u, 0u, 0u};
+            reinterpret_cast<uint4 *>(s_sub)[2 * k + 1] = uint4{lo.z, hi.z ^ 0x80000000u, lo.w, 0u};   // (lo.w: TiledBox::pad0, the subtile's reach)
         }
         for (int k = threadIdx.x; k < n_rt * 2; k += kBmCullWaves * 64) reinterpret_cast<uint4 *>(s_tile)[k] = src_tile[k];
         __syncthreads();
@@ -525,8 +527,13 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         uint32_t tested = 0;
         for (int base = 0; base < n_rt; base += 64) {
             bool tile_near = false;
-            if (base == 0) tile_near = lane < n_rt && box_gap2(whole, my_tile) <= kBmBoxCut;
-            else if (base + lane < n_rt) tile_near = box_gap2(whole, tile_at(base + lane)) <= kBmBoxCut;
+            // (against the receptor box's own reach: the full cutoff unless its atoms' rows of the potential are zero; a counting launch
+            // counts every pair inside the cutoff whatever the table holds)
+            if (base == 0) tile_near = lane < n_rt && box_gap2(whole, my_tile) <= (COUNT ? kBmBoxCut : my_tile.pad0);
+            else if (base + lane < n_rt) {
+                const TiledBox tb = tile_at(base + lane);
+                tile_near = box_gap2(whole, tb) <= (COUNT ? kBmBoxCut : tb.pad0);
+            }
             unsigned long long rtmask = __builtin_amdgcn_ballot_w64(tile_near);
             if (rtmask) {
                 // one surviving tile at a time, the next one's subtile boxes loaded while this one's are tested (the last trip loads
@@ -541,9 +548,9 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
                     rtmask &= rtmask - 1;
                     nb_next = sub_at(RT_next * 8 + bj);
 #ifdef LD_BM_DIAG_NO_TRACKED   // (diagnostic builds: timing only, wrong sums -- no block with a receptor subtile that holds a tracked atom, i.e. 1k4c's beads)
-                    const unsigned long long smask = __builtin_amdgcn_ballot_w64(bm_cull_gap2(sub_x, sub_y, sub_z, nb) <= kBmBoxCut && T->m.rec_sub_tracked[RT * 8 + bj] == 0);
+                    const unsigned long long smask = __builtin_amdgcn_ballot_w64(bm_cull_gap2(sub_x, sub_y, sub_z, nb) <= (COUNT ? kBmBoxCut : nb.cut) && T->m.rec_sub_tracked[RT * 8 + bj] == 0);
 #else
-                    const unsigned long long smask = __builtin_amdgcn_ballot_w64(bm_cull_gap2(sub_x, sub_y, sub_z, nb) <= kBmBoxCut);  // bit = ligand subtile (lane >> 3) * 8 + receptor subtile
+                    const unsigned long long smask = __builtin_amdgcn_ballot_w64(bm_cull_gap2(sub_x, sub_y, sub_z, nb) <= (COUNT ? kBmBoxCut : nb.cut));  // bit = ligand subtile (lane >> 3) * 8 + receptor subtile
 #endif
                     if (smask) {   // hit `held` of this ballot stays in lane `held` until the ballot's tiles are done
                         held_lo = (uint32_t)bm_writelane((int)(uint32_t)smask, (int)held, (int)held_lo);

@@ -130,14 +130,15 @@ __host__ __device__ inline int bm_cull_hit_tiles(int n_rt) {   // 4 while they f
 __host__ __device__ inline int bm_cull_hit_cap(int n_rt) { const int k = bm_cull_hit_tiles(n_rt); return k * n_rt > 192 ? k * n_rt : 192; }
 __host__ __device__ inline size_t bm_cull_wave_lds(int n_rt) { return ((size_t)bm_cull_hit_cap(n_rt) * 14 + (size_t)n_rt * 8 + 15) / 16 * 16; }
 __host__ __device__ inline size_t bm_cull_lds_bytes(int n_rt) { return bm_cull_lds_for(n_rt, bm_cull_hit_tiles(n_rt)); }
+constexpr float kBmBoxCutUnits2 = 14400.0f * 1.00005f;   // (8 * 15 A)^2 in record units, padded for the rounding of the box test: a receptor box's reach unless BmModel::rec_sub says less
 constexpr size_t kBmMaxPassPoses = 262144;   // a job keeps its entries' rows of the pass as 18-bit numbers (LDS)
 
 struct BmModel {
     // receptor (static image in the kappa = 8 frame; no receptor ANM on this path)
     int rec_n_real = 0, rec_n_tiles = 0;
     const PackedRecPair *rec_pairs = nullptr;   // [n_tiles*32]
-    const TiledBox *rec_sub = nullptr;          // [n_tiles*8]
-    const TiledBox *rec_tile = nullptr;         // [n_tiles]
+    const TiledBox *rec_sub = nullptr;          // [n_tiles*8]; pad0 = the subtile's reach for the culling kernel's box test, squared record units (scorer.cpp, build_bm)
+    const TiledBox *rec_tile = nullptr;         // [n_tiles]; pad0 = the largest reach of its subtiles
     const uint32_t *rec_rowoff = nullptr;       // [n_tiles*64]: byte offset of the atom's type column in a table row block
     const float *rec_ops = nullptr;             // [n_tiles*8][kBmOpsFloats]: a receptor subtile as the pair kernel's batches take it -- the centre c of its box
                                                 // and per pair record the packed operands seed - |r - c|^2, 2 (r - c)_z, _y, _x (f32, formed on the host by

@@ -943,6 +943,54 @@ void Scorer::build_bm(const ld_scorer_desc &desc) {
                 o[32] = cbx; o[33] = cby; o[34] = cbz;
             }
             M.rec_ops = arena_.upload(ops);
+            // A receptor subtile's REACH for the culling kernel's box tests, in the spare word of its box (and the largest of a tile's
+            // eight in the tile's): (8 x 15 A)^2 for every subtile whose atoms can add to a sum.  A receptor type whose rows of the
+            // potential are 0.0 against every ligand type of the complex -- all 20 bins and the read past the row at r = 15.0
+            // (src/dfire.rs:336-338: bin 20 = the next type's bin 0) -- adds nothing at any distance: a subtile of such atoms only
+            // (lightdock's membrane beads, if the DCparams at hand carries zero rows for them) is listed within the interface
+            // distance alone (d <= 3.9, i.e. r <= 2.45 A, src/dfire.rs:339) when it or the ligand holds an atom with an
+            // interface-flag slot, and never otherwise.  Exact: a block that is not listed holds no pair that changes the sum or a
+            // flag.  Counting launches test against the full cutoff (they count pairs, not values).  VERDICT r05 item 8.
+            std::vector<char> lig_has(169, 0), quiet_type(169, 1);
+            for (size_t i = 0; i < desc.ligand.n_atoms; i++) lig_has[desc.ligand.dfire_types[i]] = 1;
+            for (uint32_t r = 0; r < 169; r++)
+                for (uint32_t l = 0; l < 169 && quiet_type[r]; l++)
+                    for (uint32_t b = 0; b <= 20 && quiet_type[r] && lig_has[l]; b++) {
+                        const size_t at = (size_t)r * kDfireRowStride + (size_t)l * 20 + b;
+                        if (at >= LD_DFIRE_TABLE_LEN || desc.potential[at] != 0.0) quiet_type[r] = 0;   // (past the table's end: not ours to reason about)
+                    }
+            bool lig_tracked_any = false;
+            for (int32_t v : lig.hslot) lig_tracked_any = lig_tracked_any || v >= 0;
+            const float full_cut = kBmBoxCutUnits2, iface_cut = 400.0f * 1.00005f;   // (8 x 15 A)^2 and (8 x 2.5 A)^2 record units, padded like the full one
+            std::vector<TiledBox> ht(pad / 64);
+            hip_check(hipMemcpy(ht.data(), tile, ht.size() * sizeof(TiledBox), hipMemcpyDeviceToHost), "D2H receptor tile boxes");
+            bm_quiet_subtiles_ = 0;
+            for (size_t t = 0; t < pad / 64; t++) {
+                float tile_cut = -1.0f;
+                for (size_t sb = 0; sb < 8; sb++) {
+                    const size_t sbt = t * 8 + sb;
+                    bool quiet = true, any = false, tracked = false;
+                    for (size_t k = 0; k < 8; k++) {
+                        const uint32_t ty = rec.htype[sbt * 8 + k];
+                        if (ty == 0xffffffffu) continue;
+                        any = true;
+                        quiet = quiet && ty < 169 && quiet_type[ty];
+                        tracked = tracked || rec.hslot[sbt * 8 + k] >= 0;
+                    }
+                    float cut = full_cut;
+                    if (any && quiet) {
+                        cut = (tracked || lig_tracked_any) ? iface_cut : -1.0f;
+                        bm_quiet_subtiles_++;
+                    }
+                    hb[sbt].pad0 = cut;
+                    hb[sbt].pad1 = 0.f;
+                    tile_cut = std::max(tile_cut, cut);
+                }
+                ht[t].pad0 = tile_cut;
+                ht[t].pad1 = 0.f;
+            }
+            hip_check(hipMemcpy(sub, hb.data(), hb.size() * sizeof(TiledBox), hipMemcpyHostToDevice), "H2D receptor boxes");
+            hip_check(hipMemcpy(tile, ht.data(), ht.size() * sizeof(TiledBox), hipMemcpyHostToDevice), "H2D receptor tile boxes");
         }
     }
     if (anm) {   // the modes as the kernels read them: kappa x, f32 (BmModel)

@@ -105,6 +105,7 @@ class Scorer {
     void kernel_info(ld_kernel_info *out) const;
     // diagnostics of the last counting launch: 8x8 atom-pair blocks evaluated per pose (tiled kernel)
     void last_block_counts(size_t n, uint32_t *out_host);
+    uint32_t bm_quiet_subtiles() const { return use_bm_ ? bm_quiet_subtiles_ : 0u; }
     void enable_timing(bool on);
     void pair_kernel_time(double *total_ms, uint64_t *launches);
 
@@ -150,6 +151,7 @@ class Scorer {
     PackedLaunch packed_;
     const uint32_t *packed_lut_full_ = nullptr;  // the LUT without elided zero bins (counting launches)
     uint32_t packed_zero_bins_ = 0;
+    uint32_t bm_quiet_subtiles_ = 0;   // receptor subtiles of the block-major path whose atoms' rows of the potential are zero (build_bm)
     DeviceBuffer ws_rec_pairs_, ws_exact_;
     bool use_bm_ = false;      // DFIRE: the block-major path (kernels/dfire_bm.hpp) evaluates every batch
     BmModel bm_;

@@ -1368,3 +1368,99 @@ def test_block_major_anm_with_one_rigid_molecule_or_fewer_modes(pkg, orc, table,
     torch.cuda.synchronize()
     assert np.array_equal(d_cnt.cpu().numpy().astype(np.int64), want_n)
     assert bm_err(d_out.cpu().numpy(), want_e) < REL_TOL
+
+
+def _counts_of(torch, scorer, poses):
+    dev = torch.device("cuda:0")
+    d_poses = torch.from_numpy(np.ascontiguousarray(poses)).to(dev)
+    d_out = torch.zeros(len(poses), dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(len(poses), dtype=torch.int32, device=dev)
+    scorer.energy_batch_device(len(poses), d_poses.data_ptr(), poses.shape[1], d_out.data_ptr(), None, d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy(), d_cnt.cpu().numpy()
+
+
+@pytest.mark.gpu
+def test_membrane_beads_with_zero_rows_are_listed_within_the_interface_distance_only(pkg, orc, table):
+    """VERDICT r05 item 8.  A receptor type whose rows of the potential are 0.0 against every ligand type of the complex adds
+    nothing at any distance (src/dfire.rs:338): the culling kernel lists the blocks of a subtile of such atoms -- 1k4c's membrane
+    beads, type 167, if the DCparams at hand has zero rows for them -- within the interface distance only (src/dfire.rs:339:
+    the beads' interface flags are what the membrane penalty counts, src/dfire.rs:355-359).  Energies, membrane terms and
+    in-cutoff pair counts must stay the oracle's with the same table; a table with ONE nonzero value in those rows has no
+    such subtile."""
+    torch = pytest.importorskip("torch")
+    t = table.copy()
+    t.reshape(169, 169, 20)[167, :, :] = 0.0
+    method, rec, lig, kw = case_kwargs("1k4c", orc, t)
+    hip, cpu = pkg.Scorer.from_pdb(method, rec, lig, **kw), orc.Scorer(method, rec, lig, **kw)
+    assert hip.kernel_info()["pair_kernel_name"] == "dfire_bm_pairs"
+    quiet = hip.bm_quiet_subtiles()
+    assert 38 <= quiet <= 60, quiet          # 453 beads: 38 subtiles of beads only in the library's order (+ a few after re-ordering)
+    poses = case_positions("1k4c", orc)
+    want = cpu.energy_rows(poses)
+    stats = np.array([cpu.energy_ex_row(p)[1] for p in poses[:60]])
+    assert (stats[:, 4] > 0).sum() >= 3, "membrane-intersecting poses: the beads' interface flags must still be found"
+    assert bm_err(hip.energy_batch(poses), want) < REL_TOL
+    got, counts = _counts_of(torch, hip, poses[:60])
+    assert bm_err(got, want[:60]) < REL_TOL
+    assert np.array_equal(counts.astype(np.int64), stats[:, 5].astype(np.int64))      # a counting launch counts every pair inside the cutoff
+    # the same poses pushed into the membrane: many beads within 2.45 A of ligand atoms
+    deep = poses[:40].copy()
+    deep[:, 2] += np.linspace(-25.0, 25.0, 40)
+    assert bm_err(hip.energy_batch(deep), cpu.energy_rows(deep)) < REL_TOL
+    # one nonzero value in the beads' rows -- in the read PAST the row of the last ligand type present, at r = 15.0 exactly
+    # (bin 20 = the next type's bin 0, src/dfire.rs:336-338) -- and no subtile is quiet any more
+    lig_types = np.unique(cpu.model(1)["dfire_types"])
+    t2 = t.copy()
+    t2.reshape(-1)[167 * 169 * 20 + int(lig_types[-1]) * 20 + 20] = 1.5
+    method, rec, lig, kw = case_kwargs("1k4c", orc, t2)
+    assert pkg.Scorer.from_pdb(method, rec, lig, **kw).bm_quiet_subtiles() == 0
+    method, rec, lig, kw = case_kwargs("1k4c", orc, table)
+    assert pkg.Scorer.from_pdb(method, rec, lig, **kw).bm_quiet_subtiles() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("restraints,modes", [(False, 0), (True, 0), (True, 6)])
+def test_receptor_types_with_zero_rows_in_random_molecules(pkg, orc, table, tmp_path, restraints, modes):
+    """Random molecules, the rows of most receptor types zeroed: subtiles of such atoms only are never listed when no atom of
+    the complex has an interface-flag slot, within 2.45 A when one has (a ligand restraint's flag can be set by ANY receptor
+    atom, src/dfire.rs:339-342) -- rigid form and ANM form (the reach travels with the flexed receptor's boxes)."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(77 + modes)
+    rec, lig = str(tmp_path / "rec.pdb"), str(tmp_path / "lig.pdb")
+    rec_atoms = _random_molecule(rng, 1100, 30.0, "A")
+    lig_atoms = _random_molecule(rng, 300, 18.0, "B")
+    _write_pdb(rec, rec_atoms)
+    _write_pdb(lig, lig_atoms)
+    kw = {}
+    if restraints:
+        kw = dict(rec_active=["A.%s.%d" % (rec_atoms[0][1], rec_atoms[0][3])], lig_active=["B.%s.%d" % (lig_atoms[-1][1], lig_atoms[-1][3])])
+    n_poses, cols = 32, 7 + 2 * modes
+    if modes:
+        kw.update(use_anm=True, rec_num_anm=modes, lig_num_anm=modes,
+                  rec_nmodes=(rng.normal(size=(modes, 1100, 3)) * 0.4).ravel(), lig_nmodes=(rng.normal(size=(modes, 300, 3)) * 0.4).ravel())
+    probe = orc.Scorer("dfire", rec, lig, potential=table, **kw)
+    rec_types = np.unique(probe.model(0)["dfire_types"])
+    silent = rng.permutation(rec_types)[: int(0.93 * len(rec_types))]
+    t = table.copy()
+    t.reshape(169, 169, 20)[silent, :, :] = 0.0
+    cpu = orc.Scorer("dfire", rec, lig, potential=t, **kw)
+    hip = pkg.Scorer.from_pdb("dfire", rec, lig, potential=t, **kw)
+    assert hip.kernel_info()["pair_kernel_name"] == "dfire_bm_pairs"
+    assert hip.bm_quiet_subtiles() >= 20, hip.bm_quiet_subtiles()
+    poses = np.zeros((n_poses, cols))
+    poses[:, :3] = rng.uniform(-22, 22, (n_poses, 3))
+    poses[:6, :3] = rng.uniform(-2, 2, (6, 3))                 # overlapping: clashes, interface flags
+    q = rng.normal(size=(n_poses, 4))
+    poses[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    if modes:
+        poses[:, 7:] = rng.normal(size=(n_poses, 2 * modes)) * 2.0
+        poses[::10, 7:] *= 40.0                                  # wild poses: every block of every tile pair, through the exact path
+    want = cpu.energy_rows(poses)
+    if restraints:
+        stats = np.array([cpu.energy_ex_row(p)[1] for p in poses[:6]])
+        assert (stats[:, 2] + stats[:, 3] > 0).any(), "an overlapping pose should satisfy a restraint"
+    assert bm_err(hip.energy_batch(poses), want) < REL_TOL
+    got, counts = _counts_of(torch, hip, poses)
+    assert bm_err(got, want) < REL_TOL
+    assert np.array_equal(counts[:8].astype(np.int64), np.array([cpu.energy_ex_row(p)[1][5] for p in poses[:8]]).astype(np.int64))

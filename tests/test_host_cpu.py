@@ -371,6 +371,50 @@ def test_dfire_tile_layout(pkg, orc, table):
     assert partnered(order, perm) > 0.6
 
 
+def test_tile_order_keeps_the_blocks_a_pose_has_low(pkg, orc, table):
+    """What the atom order is FOR: the number of 8 x 8 blocks (ligand subtile x receptor subtile) whose boxes come within the
+    cutoff -- the block-major pair kernel's time is proportional to it.  The example poses of 1k4c replayed through the two
+    box tests of dfire_bm_cull on the CPU (tools/cluster_sim.py is the long form): 5 872 blocks a pose with the median splits
+    and window swaps of rounds 2-5, 5 310 with round 6's sweeps over all subtiles; the order is deterministic."""
+    from conftest import case_kwargs, case_positions
+    method, rec, lig, kw = case_kwargs("1k4c", orc, table)
+    cpu = orc.Scorer(method, rec, lig, **kw)
+
+    def ordered(m, far):
+        o, _ = pkg.dfire_tile_layout(m["coordinates"], m["dfire_types"])
+        o2, _ = pkg.dfire_tile_layout(m["coordinates"], m["dfire_types"])
+        assert np.array_equal(o, o2)
+        pad = o == 0xFFFFFFFF
+        c = m["coordinates"][np.where(pad, 0, o).astype(np.int64)].copy()
+        c[pad] = far
+        return c, ~pad
+
+    def boxes(c, v, size):
+        cc, vv = c.reshape(-1, size, 3), v.reshape(-1, size)
+        return np.where(vv[..., None], cc, np.inf).min(1), np.where(vv[..., None], cc, -np.inf).max(1)
+
+    def near(lo_a, hi_a, lo_b, hi_b):
+        gap = np.maximum(0, np.maximum(lo_a[:, None] - hi_b[None], lo_b[None] - hi_a[:, None]))
+        return (gap ** 2).sum(-1) <= 225.0
+
+    rc, rv = ordered(cpu.model(0), 1e9)
+    lc, lv = ordered(cpu.model(1), -1e9)
+    blocks = tiles = 0
+    poses = case_positions("1k4c", orc)[::20]
+    for p in poses:
+        w, x, y, z = p[3:7] / np.linalg.norm(p[3:7])
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        l = lc @ R.T + p[:3]
+        l[~lv] = -1e9
+        tile = near(*boxes(l, lv, 64), *boxes(rc, rv, 64))
+        sub = near(*boxes(l, lv, 8), *boxes(rc, rv, 8)) & np.repeat(np.repeat(tile, 8, axis=0), 8, axis=1)
+        blocks += sub.sum()
+        tiles += tile.sum()
+    assert blocks / len(poses) < 5450, blocks / len(poses)
+    assert tiles / len(poses) < 410, tiles / len(poses)
+
+
 def test_dfire_tables_equal_reference():
     """tools/check_dfire_tables.py: the reference's r3_to_numerical / ATOMNUMBER / ATOMRES / DIST_TO_BINS
     literals (src/dfire.rs:18-101) against the oracle's restated tables and the product's closed-form
