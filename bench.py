@@ -375,6 +375,10 @@ def main():
             system, case["method"].upper(), batch, n_rec, n_lig, ((", synthetic DCparams" + (" with bin 19 zeroed" if args.zero_last_bin else "") + (" with the membrane beads' rows (type 167) zeroed" if args.zero_bead_rows else "")) if table is not None else "") + (", 10 + 10 ANM modes" if case["kw"].get("use_anm") else ""))
         extra = {"poses_per_step_per_gpu": batch, "nominal_pair_tests_per_pose": info["pair_tests_per_pose"],
                  "mean_pairs_in_cutoff": float(p_cut.mean()), "mean_8x8_blocks_evaluated": blocks}
+        if case["method"] == "dfire" and scorer.bm_quiet_subtiles():
+            # (receptor subtiles whose rows of the potential are zero: listed within the interface distance only; the block
+            # count above is the counting launch's, which tests every box against the full cutoff)
+            extra["quiet_receptor_subtiles"] = scorer.bm_quiet_subtiles()
         units_per_launch = batch
         cpu_poses = poses
         pairs_for_err = p_cut if not args.no_stats else np.full(batch, float(n_rec) * n_lig)

@@ -11,6 +11,11 @@ for w in 1k4c 1ppe 1azp-dna gso-1ppe gso-1k4c 2uuy; do
   tail -1 $out/${n}_bench.json | cut -c1-110
 done
 for i in 2 3; do timeout 300 python bench.py > $out/1k4c_bench_run$i.json 2>/dev/null; tail -1 $out/1k4c_bench_run$i.json | cut -c1-110; done
+# separately labelled lines (never the headline): the synthetic table with bin 19 zeroed / with the membrane beads' rows zeroed; the headline complex at other batch sizes
+timeout 300 python bench.py --zero-last-bin --cpu-seconds 0 > $out/1k4c_zero_last_bin.json 2>/dev/null; tail -1 $out/1k4c_zero_last_bin.json | cut -c1-110
+timeout 300 python bench.py --zero-bead-rows --cpu-seconds 0 > $out/1k4c_zero_bead_rows.json 2>/dev/null; tail -1 $out/1k4c_zero_bead_rows.json | cut -c1-110
+timeout 300 python bench.py --workload gso-1k4c --zero-bead-rows --cpu-seconds 0 > $out/gso_1k4c_zero_bead_rows.json 2>/dev/null; tail -1 $out/gso_1k4c_zero_bead_rows.json | cut -c1-110
+for b in 4096 8192 16384 19456 32768 65536; do echo "1k4c, $b poses a launch: $(timeout 200 python3 bench.py --cpu-seconds 0 --batch $b 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.0f evals/s, step %.4f ms' % (d['value'], d['ms_per_step']))")"; done | tee $out/batch_sweep.txt
 for w in 1k4c 1ppe 2uuy; do
   echo "== $w" > $out/bm_wave_times_$w.txt
   timeout 200 python3 tools/bm_wave_times.py --workload $w 2>&1 | grep -v amdgpu.ids >> $out/bm_wave_times_$w.txt
