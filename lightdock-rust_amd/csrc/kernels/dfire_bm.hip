@@ -19,7 +19,7 @@
 // The LD_BM_DIAG_* blocks below are TIMING EXPERIMENTS (wrong sums by construction).  They compile only in a diagnostic build
 // (-DLD_DIAG_BUILD, which tools/build_variant.sh passes): the shipped library cannot be built with one of them by accident, and
 // tests/test_host_cpu.py checks that it carries no diagnostic switch.
-#if !defined(LD_DIAG_BUILD) && (defined(LD_BM_DIAG_ANM_COST) || defined(LD_BM_DIAG_ANM_LDS) || defined(LD_BM_DIAG_FIRST) || defined(LD_BM_DIAG_NO_ATOMIC) || defined(LD_BM_DIAG_NO_DMA) || defined(LD_BM_DIAG_NO_EXACT) || defined(LD_BM_DIAG_NO_EXACT_ATOMIC) || defined(LD_BM_DIAG_NO_PAIRS) || defined(LD_BM_DIAG_NO_PARTIAL) || defined(LD_BM_DIAG_NO_POSE) || defined(LD_BM_DIAG_NO_TRACKED) || defined(LD_BM_DIAG_ROW_OF_LANE) || defined(LD_BM_DIAG_WAIT))
+#if !defined(LD_DIAG_BUILD) && (defined(LD_BM_DIAG_ANM_COST) || defined(LD_BM_DIAG_ANM_LDS) || defined(LD_BM_DIAG_FIRST) || defined(LD_BM_DIAG_NO_ATOMIC) || defined(LD_BM_DIAG_NO_DMA) || defined(LD_BM_DIAG_NO_EXACT) || defined(LD_BM_DIAG_NO_EXACT_ATOMIC) || defined(LD_BM_DIAG_NO_PAIRS) || defined(LD_BM_DIAG_NO_PARTIAL) || defined(LD_BM_DIAG_NO_POSE) || defined(LD_BM_DIAG_NO_TRACKED) || defined(LD_BM_DIAG_ROW_OF_LANE) || defined(LD_BM_DIAG_WAIT) || defined(LD_BM_DIAG_CULL_TIMES) || defined(LD_BM_DIAG_NO_TP_ATOMIC))
 #error "LD_BM_DIAG_* needs -DLD_DIAG_BUILD (tools/build_variant.sh)"
 #endif
 
@@ -41,7 +41,7 @@ constexpr int kBmCullQueues = kBmCullQueueWords;   // (1k4c: 8 queues 695 us, 16
 constexpr float kBmBoxCut = kBmBoxCutUnits2;  // (8 * 15 A)^2 in record units, padded for the rounding of the box test
 // A receptor subtile's box as the culling kernel keeps it in LDS: per axis the pair {lo, -hi}.  With the ligand subtile's box as
 // {-hi, lo} the two differences of an axis' gap -- lo_r - hi_l and lo_l - hi_r, the values axis_gap forms -- are ONE packed add.
-struct BmCullBox {
+struct alignas(16) BmCullBox {
     v2f x, y, z;
     float cut, unused;   // the subtile's reach, squared (kBmBoxCut unless its atoms' rows of the potential are zero: scorer.cpp, build_bm)
 };
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     BmArgs *T = LD_BM_ARGS;
     // LDS: the receptor's subtile and tile boxes (read by every item; a global load per surviving tile was most of an
     // item's time), then [wave][pose of the wave][receptor tile]: block mask, 0 = not within reach
-    extern __shared__ unsigned long long s_cull[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_cull[];   // (16-byte aligned: a box is two ds_read_b128)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int n_lt = T->m.lig.n_tiles, n_rt = T->m.rec_n_tiles;
@@ -326,17 +326,31 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         return ticket;   // lane 0, on its way
     };
     uint32_t next_ticket = draw();
+#ifdef LD_BM_DIAG_CULL_TIMES   // (diagnostic builds: where a culling wave's time goes, in 10 ns ticks, into the pair kernel's debug buffer)
+    unsigned long long ct_start = __builtin_amdgcn_s_memrealtime(), ct_draw = 0, ct_box = 0, ct_loop = 0, ct_flush = 0, ct_items = 0;
+#define LD_CT(x) x
+#else
+#define LD_CT(x)
+#endif
     for (;;) {
+    LD_CT(const unsigned long long ct_a = __builtin_amdgcn_s_memrealtime();)
     const size_t item = queue_first + (uint32_t)__builtin_amdgcn_readfirstlane((int)next_ticket);
+    LD_CT(const unsigned long long ct_b = __builtin_amdgcn_s_memrealtime(); ct_draw += ct_b - ct_a;)
     if (item >= queue_end) break;
+    LD_CT(ct_items++;)
     const size_t group = item / (unsigned)n_lt;
     const int lt = (int)(item % (unsigned)n_lt);
     const size_t listed0 = group * (size_t)group_poses;
 
+    // The rigid form boxes the item's poses all at once, lane = (pose of the item, ligand subtile): below.  The ANM form keeps lane = atom
+    // (its atom's thirty mode components live in the lane's registers), pose by pose.
     const int la = lt * 64 + lane;
-    const float4 loc = reinterpret_cast<const float4 *>(T->m.lig_local)[la];
+    float4 loc = float4{0.f, 0.f, 0.f, 0.f}, sphere = loc;
+    if (ANM) {
+        loc = reinterpret_cast<const float4 *>(T->m.lig_local)[la];
+        sphere = reinterpret_cast<const float4 *>(T->m.lig_tile_sphere)[lt];
+    }
     const bool valid = loc.w != 0.f;
-    const float4 sphere = reinterpret_cast<const float4 *>(T->m.lig_tile_sphere)[lt];
     // this lane's receptor tile box (the first 64 tiles; larger receptors read the rest per pose)
     const TiledBox no_tile = TiledBox{INFINITY, INFINITY, INFINITY, 0.f, -INFINITY, -INFINITY, -INFINITY, 0.f};
     TiledBox my_tile = no_tile;
@@ -366,12 +380,12 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     float my_wild = 0.f, my_flex = 0.f;
 #pragma unroll
     for (int k = 0; k < kBmMaxModes; k++) my_amp[k] = 0.f;
-    if (my_pose >= 0) {
+    if (ANM && my_pose >= 0) {
         const float4 *ap = reinterpret_cast<const float4 *>(T->rt + (size_t)my_row * 12);
         my_a0 = ap[0];
         my_a1 = ap[1];
         my_a2 = ap[2];
-        if (ANM) {
+        {
             const float *am = T->amp + (size_t)my_row * kBmAmpFloats + kBmMaxModes;
 #pragma unroll
             for (int k = 0; k < kBmMaxModes; k++) my_amp[k] = am[k];
@@ -387,8 +401,43 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
     };
 
     // the tile's bounding sphere posed by all the item's poses at once: lane g, with the map it holds
-    float my_sx, my_sy, my_sz;
-    bm_apply(Affine{my_a0.x, my_a0.y, my_a0.z, my_a0.w, my_a1.x, my_a1.y, my_a1.z, my_a1.w, my_a2.x, my_a2.y, my_a2.z, my_a2.w}, sphere.x, sphere.y, sphere.z, my_sx, my_sy, my_sz);
+    float my_sx = 0.f, my_sy = 0.f, my_sz = 0.f;
+    if (ANM) bm_apply(Affine{my_a0.x, my_a0.y, my_a0.z, my_a0.w, my_a1.x, my_a1.y, my_a1.z, my_a1.w, my_a2.x, my_a2.y, my_a2.z, my_a2.w}, sphere.x, sphere.y, sphere.z, my_sx, my_sy, my_sz);
+
+    // ---- rigid form: the boxes of ALL the item's poses at once, lane = (pose g = lane / 8, ligand subtile s = lane % 8).  The lane poses
+    // the 8 atoms of its subtile with its pose's map (bm_apply, the operations the ANM form's lane = atom code and the exact path use:
+    // the same bits), keeps the running minima and maxima in its registers -- an atom outside the frame or a padding atom enters as
+    // the empty box, as below -- and widens them; three DPP levels over the 8 lanes of a pose give the tile's box.  Until round 6
+    // every pose of the item was boxed on its own with lane = atom: 12 v_readlane for the map, 9 multiply-adds, the frame test, 36
+    // DPP min / max for the subtile and tile boxes and a bounding-sphere pre-test in front -- ~120 vector instructions per pose and
+    // tile, over half of this kernel's; now ~45, and the poses' latencies overlap instead of following each other.
+    BoxRegs my_sub{INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}, my_whole = my_sub;
+    if constexpr (!ANM) {
+        static_assert(kBmCullPoses == 8, "lane = (pose of the item, ligand subtile)");
+        const int my_g = lane >> 3, my_s = lane & 7;
+        const bool have = __shfl((int)(my_pose >= 0), my_g, 64) != 0;   // (lane g holds pose g of the item)
+        const float4 *ap = reinterpret_cast<const float4 *>(T->rt + (have ? listed0 + (size_t)my_g : (size_t)0) * 12);
+        const float4 q0 = ap[0], q1 = ap[1], q2 = ap[2];
+        const float4 *atoms = reinterpret_cast<const float4 *>(T->m.lig_local) + ((size_t)lt * 64 + (size_t)my_s * 8);
+        float4 at[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) at[k] = atoms[k];
+        const Affine A{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float fx, fy, fz;
+            bm_apply(A, at[k].x, at[k].y, at[k].z, fx, fy, fz);
+            const bool inside = fabsf(fx) <= ubound && fabsf(fy) <= ubound && fabsf(fz) <= ubound;
+            const float pen = bm_select(__builtin_amdgcn_ballot_w64(have && at[k].w != 0.f && inside), 0.0f, INFINITY);
+            my_sub.lox = fminf(my_sub.lox, fx + pen); my_sub.loy = fminf(my_sub.loy, fy + pen); my_sub.loz = fminf(my_sub.loz, fz + pen);
+            my_sub.hix = fmaxf(my_sub.hix, fx - pen); my_sub.hiy = fmaxf(my_sub.hiy, fy - pen); my_sub.hiz = fmaxf(my_sub.hiz, fz - pen);
+        }
+        const float wide = pad + 2.384185791015625e-07f * ubound;   // (as below)
+        my_sub.lox -= wide; my_sub.loy -= wide; my_sub.loz -= wide;
+        my_sub.hix += wide; my_sub.hiy += wide; my_sub.hiz += wide;
+        my_whole = my_sub;
+        box_reduce8(my_whole);   // (every lane of pose g: the tile's box in pose g)
+    }
 
     uint32_t n_hits = 0;                 // wave-uniform: hits listed and not flushed yet
     // ---- the list -> entries.  One LDS atomic per hit (its place among the wave's hits of the tile pair), ONE global atomic per
@@ -403,7 +452,11 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (int k = lane; k < n_rt; k += 64) {
             const uint32_t total = s_cnt[k];
+#ifdef LD_BM_DIAG_NO_TP_ATOMIC   // (diagnostic builds: timing only, wrong lists -- what the culling kernel takes without its returning atomics on the tile pairs' counters)
+            if (total) { s_base[k] = (uint32_t)(listed0 % 1024u); T->tp_count[(size_t)lt * n_rt + k] = s_base[k] + total; }
+#else
             if (total) s_base[k] = atomicAdd(&T->tp_count[(size_t)lt * n_rt + k], total);
+#endif
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (uint32_t h0 = 0; h0 < n_hits; h0 += 64) {
@@ -424,6 +477,7 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         n_hits = 0;
     };
 
+    LD_CT(asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); asm volatile("" :: "v"(my_whole.lox), "v"(my_whole.hiz)); const unsigned long long ct_c = __builtin_amdgcn_s_memrealtime(); ct_box += ct_c - ct_b;)
     long long pose_of[kBmCullPoses];   // wave-uniform
 #pragma unroll
     for (int g = 0; g < kBmCullPoses; g++) {
@@ -467,61 +521,72 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         }
         auto tile_at = [&](int i) { return ANM ? tiles_g[i] : s_tile[i]; };
         auto sub_at = [&](int i) { return ANM ? subs_g[i] : s_sub[i]; };   // subtile i of the receptor as {lo, -hi} pairs
-        {   // A tile whose bounding sphere stays beyond the cutoff of every receptor tile's box has nothing to list (most tiles
-            // of a large ligand, in most poses): one point posed and one test per receptor tile instead of 64 atoms posed,
-            // their boxes and the box tests.
-            const float sx = pose_lane(my_sx, g), sy = pose_lane(my_sy, g), sz = pose_lane(my_sz, g);
-            const float reach = 120.0f * 1.0001f + sphere.w + pad + flex_reach;   // (8 * 15 A, the sphere's radius, the affine map's error; ANM: what the modes can add)
-            bool any_near = false;
-            for (int base = 0; base < n_rt && !any_near; base += 64) {
-                const TiledBox tb = base == 0 ? my_tile : (base + lane < n_rt ? tile_at(base + lane) : my_tile);
-                const float gx = fmaxf(0.f, fmaxf(tb.lox - sx, sx - tb.hix));
-                const float gy = fmaxf(0.f, fmaxf(tb.loy - sy, sy - tb.hiy));
-                const float gz = fmaxf(0.f, fmaxf(tb.loz - sz, sz - tb.hiz));
-                any_near = __builtin_amdgcn_ballot_w64(base + lane < n_rt && gx * gx + gy * gy + gz * gz <= reach * reach) != 0ull;
+        BoxRegs sub, whole;   // lane: the box of ligand subtile lane / 8 in pose g; wave-uniform: the tile's
+        if constexpr (ANM) {
+            {   // A tile whose bounding sphere stays beyond the cutoff of every receptor tile's box has nothing to list (most tiles
+                // of a large ligand, in most poses): one point posed and one test per receptor tile instead of 64 atoms posed,
+                // their boxes and the box tests.
+                const float sx = pose_lane(my_sx, g), sy = pose_lane(my_sy, g), sz = pose_lane(my_sz, g);
+                const float reach = 120.0f * 1.0001f + sphere.w + pad + flex_reach;   // (8 * 15 A, the sphere's radius, the affine map's error; ANM: what the modes can add)
+                bool any_near = false;
+                for (int base = 0; base < n_rt && !any_near; base += 64) {
+                    const TiledBox tb = base == 0 ? my_tile : (base + lane < n_rt ? tile_at(base + lane) : my_tile);
+                    const float gx = fmaxf(0.f, fmaxf(tb.lox - sx, sx - tb.hix));
+                    const float gy = fmaxf(0.f, fmaxf(tb.loy - sy, sy - tb.hiy));
+                    const float gz = fmaxf(0.f, fmaxf(tb.loz - sz, sz - tb.hiz));
+                    any_near = __builtin_amdgcn_ballot_w64(base + lane < n_rt && gx * gx + gy * gy + gz * gz <= reach * reach) != 0ull;
+                }
+                if (!any_near) {
+                    if (COUNT && lane == 0) T->tile_tested[(listed0 + g) * (size_t)n_lt + lt] = 0;
+                    continue;
+                }
             }
-            if (!any_near) {
-                if (COUNT && lane == 0) T->tile_tested[(listed0 + g) * (size_t)n_lt + lt] = 0;
-                continue;
+            const Affine A = affine_of(g);
+            float fx, fy, fz;
+            bm_apply(A, loc.x, loc.y, loc.z, fx, fy, fz);
+            if (ANM) {   // + sum_k amplitude_k mode_k (src/dfire.rs:288-301: after the rotation and translation, in the receptor's frame)
+    #pragma unroll
+                for (int k = 0; k < kBmMaxModes; k++) {
+                    const float c = pose_lane(my_amp[k], g);
+                    fx = __builtin_fmaf(c, mode_x[k], fx);
+                    fy = __builtin_fmaf(c, mode_y[k], fy);
+                    fz = __builtin_fmaf(c, mode_z[k], fz);
+                }
             }
-        }
-        const Affine A = affine_of(g);
-        float fx, fy, fz;
-        bm_apply(A, loc.x, loc.y, loc.z, fx, fy, fz);
-        if (ANM) {   // + sum_k amplitude_k mode_k (src/dfire.rs:288-301: after the rotation and translation, in the receptor's frame)
-#pragma unroll
-            for (int k = 0; k < kBmMaxModes; k++) {
-                const float c = pose_lane(my_amp[k], g);
-                fx = __builtin_fmaf(c, mode_x[k], fx);
-                fy = __builtin_fmaf(c, mode_y[k], fy);
-                fz = __builtin_fmaf(c, mode_z[k], fz);
-            }
-        }
-        const bool inside = fabsf(fx) <= ubound && fabsf(fy) <= ubound && fabsf(fz) <= ubound;
+            const bool inside = fabsf(fx) <= ubound && fabsf(fy) <= ubound && fabsf(fz) <= ubound;
 
-        // An atom outside the frame is more than the cutoff away from every receptor atom (the frame holds the receptor's
-        // box + 16 A): it joins no box; the pairs it still meets inside blocks of its subtile read "miss", as they must.
-        // The lane's point as a box, an excluded lane's as the empty box (lo = +inf, hi = -inf): ONE select -- a penalty of 0 or
-        // +inf added for the minima, subtracted for the maxima -- instead of six.  (A select on VCC, `v_cndmask_b32_e32`, holds the
-        // vector port for 23 cycles on gfx950, five plain instructions' worth -- tools/microbench/valu_rate.hip,
-        // profiles/r06_valu_issue_rates.txt --; the form with the mask in a scalar register pair costs 4.4: bm_select.  An excluded
-        // lane whose coordinate is itself infinite or NaN yields NaN on one side: v_min / v_max return the other operand, i.e. it
-        // still joins no box.)
-        const float pen = bm_select(__builtin_amdgcn_ballot_w64(valid && inside), 0.0f, INFINITY);
-        BoxRegs sub{fx + pen, fy + pen, fz + pen, fx - pen, fy - pen, fz - pen};
-        box_reduce8(sub);
-        {   // widen: the f32 positions are within box_pad of the exactly posed ones; the boxes are built from fl32(u), the true u within
-            // 2^-24 |u| of it: |u| <= ubound for every atom in a box, so 2^-22 ubound on top of the pad is outwards (the relative
-            // widening atom by atom, box_widen, was 18 vector instructions a pose and tile; an infinite side stays infinite)
-            const float wide = pad + 2.384185791015625e-07f * ubound;
-            sub.lox -= wide; sub.loy -= wide; sub.loz -= wide;
-            sub.hix += wide; sub.hiy += wide; sub.hiz += wide;
+            // An atom outside the frame is more than the cutoff away from every receptor atom (the frame holds the receptor's
+            // box + 16 A): it joins no box; the pairs it still meets inside blocks of its subtile read "miss", as they must.
+            // The lane's point as a box, an excluded lane's as the empty box (lo = +inf, hi = -inf): ONE select -- a penalty of 0 or
+            // +inf added for the minima, subtracted for the maxima -- instead of six.  (A select on VCC, `v_cndmask_b32_e32`, holds the
+            // vector port for 23 cycles on gfx950, five plain instructions' worth -- tools/microbench/valu_rate.hip,
+            // profiles/r06_valu_issue_rates.txt --; the form with the mask in a scalar register pair costs 4.4: bm_select.  An excluded
+            // lane whose coordinate is itself infinite or NaN yields NaN on one side: v_min / v_max return the other operand, i.e. it
+            // still joins no box.)
+            const float pen = bm_select(__builtin_amdgcn_ballot_w64(valid && inside), 0.0f, INFINITY);
+            sub = BoxRegs{fx + pen, fy + pen, fz + pen, fx - pen, fy - pen, fz - pen};
+            box_reduce8(sub);
+            {   // widen: the f32 positions are within box_pad of the exactly posed ones; the boxes are built from fl32(u), the true u within
+                // 2^-24 |u| of it: |u| <= ubound for every atom in a box, so 2^-22 ubound on top of the pad is outwards (the relative
+                // widening atom by atom, box_widen, was 18 vector instructions a pose and tile; an infinite side stays infinite)
+                const float wide = pad + 2.384185791015625e-07f * ubound;
+                sub.lox -= wide; sub.loy -= wide; sub.loz -= wide;
+                sub.hix += wide; sub.hiy += wide; sub.hiz += wide;
+            }
+            whole = sub;   // (widening is monotone: the union of the widened subtile boxes IS the widened tile box)
+            box_reduce64_from8(whole);
+            whole.lox = lane63_f32(whole.lox); whole.loy = lane63_f32(whole.loy); whole.loz = lane63_f32(whole.loz);
+            whole.hix = lane63_f32(whole.hix); whole.hiy = lane63_f32(whole.hiy); whole.hiz = lane63_f32(whole.hiz);
+        } else {
+            // (boxed above for all the item's poses: the subtile's box from the lane that holds it -- six ds_bpermute, the LDS crossbar,
+            // not the vector port --, the tile's from the first lane of the pose)
+            const int src = g * 8 + (lane >> 3);
+            sub.lox = __shfl(my_sub.lox, src, 64); sub.loy = __shfl(my_sub.loy, src, 64); sub.loz = __shfl(my_sub.loz, src, 64);
+            sub.hix = __shfl(my_sub.hix, src, 64); sub.hiy = __shfl(my_sub.hiy, src, 64); sub.hiz = __shfl(my_sub.hiz, src, 64);
+            whole.lox = pose_lane(my_whole.lox, g * 8); whole.loy = pose_lane(my_whole.loy, g * 8); whole.loz = pose_lane(my_whole.loz, g * 8);
+            whole.hix = pose_lane(my_whole.hix, g * 8); whole.hiy = pose_lane(my_whole.hiy, g * 8); whole.hiz = pose_lane(my_whole.hiz, g * 8);
         }
         const v2f sub_x{-sub.hix, sub.lox}, sub_y{-sub.hiy, sub.loy}, sub_z{-sub.hiz, sub.loz};
-        BoxRegs whole = sub;   // (widening is monotone: the union of the widened subtile boxes IS the widened tile box)
-        box_reduce64_from8(whole);
-        whole.lox = lane63_f32(whole.lox); whole.loy = lane63_f32(whole.loy); whole.loz = lane63_f32(whole.loz);
-        whole.hix = lane63_f32(whole.hix); whole.hiy = lane63_f32(whole.hiy); whole.hiz = lane63_f32(whole.hiz);
 
         // 64 x 64 tile boxes, 64 receptor tiles per ballot; then the 8 x 8 subtile boxes of every surviving tile
         uint32_t tested = 0;
@@ -570,9 +635,21 @@ __global__ __launch_bounds__(kBmCullWaves * 64) void dfire_bm_cull(const BmLaunc
         }
         if (COUNT && lane == 0) T->tile_tested[(listed0 + g) * (size_t)n_lt + lt] = tested;
     }
+    LD_CT(const unsigned long long ct_d = __builtin_amdgcn_s_memrealtime(); ct_loop += ct_d - ct_c;)
     next_ticket = draw();   // (here, not at the item's start: memory operations return in order, and the item's loads would wait for it)
     flush();
+    LD_CT(ct_flush += __builtin_amdgcn_s_memrealtime() - ct_d;)
     }
+#ifdef LD_BM_DIAG_CULL_TIMES
+    {
+        const size_t w = (size_t)blockIdx.x * kBmCullWaves + wave;
+        if (T->debug != nullptr && lane == 0 && w % 5 == 0 && w / 5 < 2048) {   // (every fifth wave: all workgroups of the launch are sampled)
+            unsigned long long *d = T->debug + w / 5 * 8;
+            d[0] = ct_start; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = ct_items; d[3] = ct_draw; d[4] = ct_box; d[5] = ct_loop; d[6] = ct_flush; d[7] = w;
+        }
+    }
+#endif
+#undef LD_CT
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1568,6 +1645,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         if (queued) bm_exact_pairs(T, queue, queued, lane);
         if (DEBUG) dbg_t_drain += now() - td;
     }
+#ifndef LD_BM_DIAG_CULL_TIMES
     if (DEBUG && T->debug != nullptr && lane == 0) {
         unsigned long long *d = T->debug + ((size_t)blockIdx.x * kBmWaves + wave) * 8;
         d[0] = dbg_t0;
@@ -1579,6 +1657,7 @@ __global__ __launch_bounds__(kBmWaves * 64, kBmGroupsPerCu) void dfire_bm_pairs(
         d[6] = dbg_t_block;
         d[7] = dbg_t_scan;
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
